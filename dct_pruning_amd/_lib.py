@@ -1,0 +1,69 @@
+"""ctypes binding of libdctscore.so (include/dctscore.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, every
+entry point raises. A CPU stand-in here would make parity claims meaningless.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdctscore.so")
+ABI_VERSION = 1
+
+_lock = threading.Lock()
+_lib = None
+
+_i64, _i32, _vp, _sz = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t
+
+# symbol -> (restype, argtypes); mirrors include/dctscore.h one to one
+SIGNATURES = {
+    "dcts_version": (ctypes.c_int, []),
+    "dcts_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "dcts_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "dcts_has_codelet": (ctypes.c_int, [_i64, _i64]),
+    "dcts_energy_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                       _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dcts_energy_f32_ex": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                          _i32, _i32, _i32, _vp, _vp, _sz, _vp, _i32]),
+    "dcts_dct2d_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                      _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "dcts_dct2d_f32_ex": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                         _i32, _i32, _i32, _vp, _vp, _sz, _vp, _i32]),
+    "dcts_batch_sum_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+}
+
+
+class DctScoreError(RuntimeError):
+    """A libdctscore entry point returned a non-zero code."""
+
+    def __init__(self, code, text):
+        super().__init__("libdctscore error %d: %s" % (code, text))
+        self.code = code
+
+
+def load():
+    """Load libdctscore.so once and declare every prototype; raises if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                "libdctscore.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dct_pruning_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.dcts_version()
+        if got != ABI_VERSION:
+            raise ImportError("libdctscore ABI %d != expected %d" % (got, ABI_VERSION))
+        _lib = lib
+        return lib
+
+
+def check(code):
+    if code != 0:
+        raise DctScoreError(code, load().dcts_strerror(code).decode())

@@ -1,0 +1,8 @@
+// Tile edge lengths that get a register-resident codelet kernel (edges AFTER the cv2-style
+// odd front pad). Sources: SURVEY.md Appendix C — VGG 32/16/8/4/2, ResNet-56/110 and
+// DenseNet 32/16/8, GoogLeNet 32/16/8, ResNet-50 56/28/14/7, U2-Net-p 36/18/9 (+10 via
+// the odd pad) and its 320-crop family 40/20/10; 64 and 48 are the natural power-of-two /
+// 3*2^k fillers.
+#pragma once
+#define DCTS_CODELET_SIZES(X) \
+  X(2) X(4) X(7) X(8) X(9) X(10) X(14) X(16) X(18) X(20) X(28) X(32) X(36) X(40) X(48) X(56) X(64)

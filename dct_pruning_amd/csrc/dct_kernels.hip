@@ -1,0 +1,480 @@
+// dct_kernels.hip — gfx950 kernels behind include/dctscore.h.
+//
+// Replaces the per-map Python loop of the reference hooks (utils/common.py:262-309):
+//   c = [dct.dct_2d(output[i,j,:,:], norm='ortho') ...]; torch.sum(dct.mul(dct)).item()
+// with one launch per hooked tensor: every (sample, channel) map gets its orthonormal
+// 2-D DCT-II and the squared coefficients are reduced to one fp32 energy per map.
+//
+// Two kernel families:
+//   k_energy_codelet  maps with both edges <= 64 that have a codelet (codelet_sizes.h).
+//                     One wave owns floor(64/edge) maps. Pass 1: lane = column, the lane
+//                     holds the whole column in VGPRs (coalesced dword loads straight
+//                     from HBM, row r of a map is one contiguous segment across lanes) and
+//                     runs a straight-line factorised DCT-II (dct_codelets.hpp). The
+//                     tile is transposed through a per-wave LDS slab (odd row stride ->
+//                     conflict-free both ways). Pass 2: lane = row, second codelet, the
+//                     squares are summed in-lane and then across the map's lanes with a
+//                     segmented wave shuffle reduction. HBM traffic = the algorithmic
+//                     4*H*W + 4 bytes per map; LDS traffic = one write + one read per
+//                     element.
+//   k_energy_direct   any (H, W) <= DCTS_MAX_EDGE: separable cosine-matrix transform with
+//                     the basis block staged in LDS; intermediate tile in a caller-provided
+//                     workspace (L2-resident). O(H*W*(H+W)) flops per map: the correct
+//                     fallback, compute-bound for large tiles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dctscore.h"
+#include "codelet_sizes.h"
+#include "dct_codelets.hpp"
+
+namespace {
+
+struct MapGeom {
+  const float* x;
+  long long nmaps;    // N * c_count
+  long long strideN;  // elements
+  long long strideC;  // elements
+  long long strideH;  // elements (direct kernel only; codelet kernels require == W)
+  int c_count;
+  int c_begin;
+  int H, W;           // data dims (before the odd front pad)
+  int contiguous;     // 1: map m starts at x + c_begin*strideC + m*strideC (no div needed)
+};
+
+__device__ __forceinline__ const float* map_base(const MapGeom& g, long long m) {
+  if (g.contiguous) return g.x + (long long)g.c_begin * g.strideC + m * g.strideC;
+  const long long n = m / g.c_count;
+  const long long j = m - n * g.c_count;
+  return g.x + n * g.strideN + (g.c_begin + j) * g.strideC;
+}
+
+// ---------------------------------------------------------------------------------------
+// codelet family
+// ---------------------------------------------------------------------------------------
+template <int HP, int WP>
+struct CodeletCfg {
+  static constexpr int EDGE = HP > WP ? HP : WP;
+  static constexpr int G = 64 / EDGE;           // maps per wave per iteration
+  static constexpr int S = WP | 1;              // odd LDS row stride (floats)
+  static constexpr int MAP_LDS = HP * S;        // floats per map in the transpose slab
+  static constexpr int WAVE_LDS = G * MAP_LDS;  // floats per wave
+  // waves per workgroup: keep a workgroup's slab <= 48 KiB so >= 3 workgroups fit a CU
+  static constexpr int WAVES = (WAVE_LDS * 4 * 4 <= 49152) ? 4 : ((WAVE_LDS * 4 * 2 <= 49152) ? 2 : 1);
+};
+
+template <int HP, int WP, int PAD, bool STORE_COEFF>
+__global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_codelet(
+    MapGeom g, float* __restrict__ out) {
+  using Cfg = CodeletCfg<HP, WP>;
+  constexpr int G = Cfg::G, S = Cfg::S, MAP_LDS = Cfg::MAP_LDS, WAVES = Cfg::WAVES;
+  constexpr int W = WP - PAD;  // data row length == row stride (dense rows)
+  __shared__ float slab[WAVES][Cfg::WAVE_LDS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* my = slab[wave];
+
+  // pass-1 role: (map g1, column c); pass-2 role: (map g2, row k)
+  const int g1 = lane / WP, c = lane - g1 * WP;
+  const int g2 = lane / HP, k = lane - g2 * HP;
+  const bool act1 = g1 < G, act2 = g2 < G;
+
+  const long long ngroups = (g.nmaps + G - 1) / G;
+  const long long wave_gid = (long long)blockIdx.x * WAVES + wave;
+  const long long nwaves = (long long)gridDim.x * WAVES;
+
+  for (long long grp = wave_gid; grp < ngroups; grp += nwaves) {
+    // ---- pass 1: column DCT-II of length HP, lane = column -------------------------
+    const long long m1 = grp * G + g1;
+    float xr[HP];
+    const bool ld = act1 && m1 < g.nmaps && c >= PAD;
+    if (ld) {
+      const float* p = map_base(g, m1) + (c - PAD);
+      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int r = decltype(i)::value;
+        if constexpr (r < PAD)
+          xr[r] = 0.f;
+        else
+          xr[r] = p[(r - PAD) * W];
+      });
+    } else {
+      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE { xr[decltype(i)::value] = 0.f; });
+    }
+    float y[HP];
+    dcts::Dct2<HP>::run(xr, y);
+    y[0] *= dcts::kInvSqrt2;
+    if (act1) {
+      float* dst = my + g1 * MAP_LDS + c;
+      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int kk = decltype(i)::value;
+        dst[kk * S] = y[kk];
+      });
+    }
+    // the wave's own LDS traffic is in order; only the compiler must not reorder
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- pass 2: row DCT-II of length WP, lane = row --------------------------------
+    float z[WP], w[WP];
+    {
+      const float* src = my + (act2 ? g2 : 0) * MAP_LDS + (act2 ? k : 0) * S;
+      dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int cc = decltype(i)::value;
+        z[cc] = src[cc];
+      });
+    }
+    dcts::Dct2<WP>::run(z, w);
+    w[0] *= dcts::kInvSqrt2;
+    const long long m2 = grp * G + g2;
+    if constexpr (STORE_COEFF) {
+      // debug/parity path: out is [nmaps][HP][WP] orthonormal coefficients
+      if (act2 && m2 < g.nmaps) {
+        constexpr float sc = float(2.0 / dcts::cx_sqrt(double(HP) * double(WP)));
+        float* o = out + (m2 * HP + k) * WP;
+        dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
+          constexpr int l = decltype(i)::value;
+          o[l] = w[l] * sc;
+        });
+      }
+    } else {
+      float e = 0.f;
+      dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int l = decltype(i)::value;
+        e = fmaf(w[l], w[l], e);
+      });
+      if (!act2) e = 0.f;
+      // segmented reduction over the HP lanes of each map (lane k == 0 ends with the sum)
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        if (off < HP) {
+          const float t = __shfl_down(e, off, 64);
+          if (k + off < HP) e += t;
+        }
+      }
+      if (act2 && k == 0 && m2 < g.nmaps) {
+        constexpr float sc = float(4.0 / (double(HP) * double(WP)));
+        out[m2] = e * sc;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// direct family: basis tables + separable transform
+// ---------------------------------------------------------------------------------------
+// Bt[r*n + k] = s_k cos(pi (2r+1) k / (2n)), s_0 = sqrt(1/n), s_k = sqrt(2/n)
+__global__ void k_basis(float* __restrict__ Bt, int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  const int r = idx / n, k = idx - r * n;
+  const long long num = ((long long)(2 * r + 1) * k) % (4LL * n);
+  const double cv = cospi(double(num) / double(2 * n));
+  const double s = (k == 0) ? sqrt(1.0 / double(n)) : sqrt(2.0 / double(n));
+  Bt[idx] = float(cv * s);
+}
+
+constexpr int kDirectThreads = 256;
+constexpr int kKB = 8;  // output rows per basis block
+
+template <bool STORE_COEFF>
+__global__ __launch_bounds__(kDirectThreads) void k_energy_direct(
+    MapGeom g, int pad, const float* __restrict__ CHt, const float* __restrict__ CWt,
+    float* __restrict__ T, float* __restrict__ out) {
+  const int HP = g.H + pad, WP = g.W + pad;
+  __shared__ __attribute__((aligned(16))) float Bs[DCTS_MAX_EDGE][kKB];
+  __shared__ float red[kDirectThreads / 64];
+  const int tid = threadIdx.x;
+  float* Tm = T + (size_t)blockIdx.x * HP * WP;
+
+  for (long long m = blockIdx.x; m < g.nmaps; m += gridDim.x) {
+    const float* xm = map_base(g, m);
+    // ---- phase 1: Tm[k][c] = sum_r CH[k][r] x'[r][c] --------------------------------
+    for (int k0 = 0; k0 < HP; k0 += kKB) {
+      __syncthreads();
+      for (int i = tid; i < HP * kKB; i += kDirectThreads) {
+        const int r = i / kKB, kk = i - r * kKB;
+        Bs[r][kk] = (k0 + kk < HP) ? CHt[r * HP + k0 + kk] : 0.f;
+      }
+      __syncthreads();
+      for (int c = tid; c < WP; c += kDirectThreads) {
+        float acc[kKB];
+#pragma unroll
+        for (int kk = 0; kk < kKB; ++kk) acc[kk] = 0.f;
+        if (c >= pad) {
+          const float* col = xm + (c - pad);
+          for (int r = pad; r < HP; ++r) {
+            const float xv = col[(long long)(r - pad) * g.strideH];
+            const float4 b0 = *reinterpret_cast<const float4*>(&Bs[r][0]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&Bs[r][4]);
+            acc[0] = fmaf(xv, b0.x, acc[0]);
+            acc[1] = fmaf(xv, b0.y, acc[1]);
+            acc[2] = fmaf(xv, b0.z, acc[2]);
+            acc[3] = fmaf(xv, b0.w, acc[3]);
+            acc[4] = fmaf(xv, b1.x, acc[4]);
+            acc[5] = fmaf(xv, b1.y, acc[5]);
+            acc[6] = fmaf(xv, b1.z, acc[6]);
+            acc[7] = fmaf(xv, b1.w, acc[7]);
+          }
+        }
+#pragma unroll
+        for (int kk = 0; kk < kKB; ++kk)
+          if (k0 + kk < HP) Tm[(k0 + kk) * WP + c] = acc[kk];
+      }
+    }
+    // ---- phase 2: Y[k][l] = sum_c Tm[k][c] CW[l][c]; energy += Y^2 --------------------
+    float e = 0.f;
+    for (int k0 = 0; k0 < HP; k0 += kKB) {
+      __syncthreads();  // also orders phase-1 global stores before these loads (same CU)
+      for (int i = tid; i < WP * kKB; i += kDirectThreads) {
+        const int cc = i / kKB, kk = i - cc * kKB;
+        Bs[cc][kk] = (k0 + kk < HP) ? Tm[(k0 + kk) * WP + cc] : 0.f;
+      }
+      __syncthreads();
+      for (int l = tid; l < WP; l += kDirectThreads) {
+        float acc[kKB];
+#pragma unroll
+        for (int kk = 0; kk < kKB; ++kk) acc[kk] = 0.f;
+        for (int cc = 0; cc < WP; ++cc) {
+          const float wv = CWt[cc * WP + l];
+          const float4 b0 = *reinterpret_cast<const float4*>(&Bs[cc][0]);
+          const float4 b1 = *reinterpret_cast<const float4*>(&Bs[cc][4]);
+          acc[0] = fmaf(wv, b0.x, acc[0]);
+          acc[1] = fmaf(wv, b0.y, acc[1]);
+          acc[2] = fmaf(wv, b0.z, acc[2]);
+          acc[3] = fmaf(wv, b0.w, acc[3]);
+          acc[4] = fmaf(wv, b1.x, acc[4]);
+          acc[5] = fmaf(wv, b1.y, acc[5]);
+          acc[6] = fmaf(wv, b1.z, acc[6]);
+          acc[7] = fmaf(wv, b1.w, acc[7]);
+        }
+#pragma unroll
+        for (int kk = 0; kk < kKB; ++kk) {
+          if (k0 + kk < HP) {
+            if constexpr (STORE_COEFF)
+              out[(m * HP + k0 + kk) * WP + l] = acc[kk];
+            else
+              e = fmaf(acc[kk], acc[kk], e);
+          }
+        }
+      }
+    }
+    if constexpr (!STORE_COEFF) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) e += __shfl_down(e, off, 64);
+      __syncthreads();
+      if ((tid & 63) == 0) red[tid >> 6] = e;
+      __syncthreads();
+      if (tid == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < kDirectThreads / 64; ++i) s += red[i];
+        out[m] = s;
+      }
+    }
+  }
+}
+
+// out_c[j] = sum_n e[n*C + j], n ascending
+__global__ void k_batch_sum(const float* __restrict__ e, long long N, long long C,
+                            float* __restrict__ out_c) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= C) return;
+  float s = 0.f;
+  for (long long n = 0; n < N; ++n) s += e[n * C + j];
+  out_c[j] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+constexpr int kDirectGridCap = 512;
+constexpr int kNumCU = 256;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DirectWs {
+  size_t off_ch, off_cw, off_t, total;
+  int grid;
+};
+DirectWs direct_ws(long long nmaps, int HP, int WP) {
+  DirectWs w;
+  w.grid = (int)(nmaps < kDirectGridCap ? (nmaps > 0 ? nmaps : 1) : kDirectGridCap);
+  w.off_ch = 0;
+  w.off_cw = align_up(w.off_ch + (size_t)HP * HP * 4, 256);
+  w.off_t = align_up(w.off_cw + (size_t)WP * WP * 4, 256);
+  w.total = align_up(w.off_t + (size_t)w.grid * HP * WP * 4, 256);
+  return w;
+}
+
+template <int HP, int WP, int PAD, bool STORE>
+int launch_codelet(const MapGeom& g, float* out, hipStream_t st) {
+  using Cfg = CodeletCfg<HP, WP>;
+  const long long ngroups = (g.nmaps + Cfg::G - 1) / Cfg::G;
+  long long blocks = (ngroups + Cfg::WAVES - 1) / Cfg::WAVES;
+  const long long cap = (long long)kNumCU * 32 / Cfg::WAVES;  // one full residency of waves
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((k_energy_codelet<HP, WP, PAD, STORE>), dim3((unsigned)blocks),
+                     dim3(64 * Cfg::WAVES), 0, st, g, out);
+  return (int)hipGetLastError();
+}
+
+template <bool STORE>
+int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipStream_t st) {
+  if (HP != WP) return DCTS_E_UNSUPPORTED;
+#define DCTS_CASE(N)                                                          \
+  case N:                                                                     \
+    if (pad) {                                                                \
+      if constexpr ((N % 2) == 0 && N >= 2)                                   \
+        return launch_codelet<N, N, 1, STORE>(g, out, st);                    \
+      else                                                                    \
+        return DCTS_E_UNSUPPORTED;                                            \
+    }                                                                         \
+    return launch_codelet<N, N, 0, STORE>(g, out, st);
+  switch (HP) {
+    DCTS_CODELET_SIZES(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+
+bool has_codelet(long long HP, long long WP) {
+  if (HP != WP) return false;
+#define DCTS_CASE(N) \
+  if (HP == N) return true;
+  DCTS_CODELET_SIZES(DCTS_CASE)
+#undef DCTS_CASE
+  return false;
+}
+
+template <bool STORE>
+int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_t strideN,
+        int64_t strideC, int64_t strideH, int64_t strideW, int32_t c_begin, int32_t c_count,
+        int32_t pad_front_if_odd, float* out, void* workspace, size_t workspace_bytes,
+        void* stream, int32_t algo) {
+  if (!x || !out) return DCTS_E_NULL;
+  if (N <= 0 || C_total <= 0 || H <= 0 || W <= 0) return DCTS_E_SHAPE;
+  if (c_count <= 0 || c_begin < 0 || (int64_t)c_begin + c_count > C_total) return DCTS_E_CHANNELS;
+  if (strideW != 1 || strideH < W) return DCTS_E_STRIDE;
+  if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(out) & 3)) return DCTS_E_ALIGN;
+  const int pad = (pad_front_if_odd && (H % 2 != 0)) ? 1 : 0;
+  const int64_t HP = H + pad, WP = W + pad;
+  if (HP > DCTS_MAX_EDGE || WP > DCTS_MAX_EDGE) return DCTS_E_SHAPE;
+  if (N * (int64_t)c_count >= (1LL << 40)) return DCTS_E_SHAPE;
+
+  MapGeom g;
+  g.x = x;
+  g.nmaps = N * (int64_t)c_count;
+  g.strideN = strideN;
+  g.strideC = strideC;
+  g.strideH = strideH;
+  g.c_count = c_count;
+  g.c_begin = c_begin;
+  g.H = (int)H;
+  g.W = (int)W;
+  g.contiguous = (N == 1 || strideN == (int64_t)c_count * strideC) ? 1 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+  const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
+  if (algo == DCTS_ALGO_CODELET && !codelet_ok) return DCTS_E_UNSUPPORTED;
+  if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET)
+    return DCTS_E_UNSUPPORTED;
+  if (codelet_ok && algo != DCTS_ALGO_DIRECT)
+    return dispatch_codelet<STORE>((int)HP, (int)WP, pad, g, out, st);
+
+  const DirectWs ws = direct_ws(g.nmaps, (int)HP, (int)WP);
+  if (!workspace) return ws.total ? DCTS_E_WORKSPACE : DCTS_E_NULL;
+  if (workspace_bytes < ws.total) return DCTS_E_WORKSPACE;
+  char* wsp = reinterpret_cast<char*>(workspace);
+  float* CHt = reinterpret_cast<float*>(wsp + ws.off_ch);
+  float* CWt = reinterpret_cast<float*>(wsp + ws.off_cw);
+  float* T = reinterpret_cast<float*>(wsp + ws.off_t);
+  hipLaunchKernelGGL(k_basis, dim3((unsigned)((HP * HP + 255) / 256)), dim3(256), 0, st, CHt, (int)HP);
+  hipLaunchKernelGGL(k_basis, dim3((unsigned)((WP * WP + 255) / 256)), dim3(256), 0, st, CWt, (int)WP);
+  hipLaunchKernelGGL((k_energy_direct<STORE>), dim3((unsigned)ws.grid), dim3(kDirectThreads), 0, st,
+                     g, pad, CHt, CWt, T, out);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcts_version(void) { return DCTS_ABI_VERSION; }
+
+const char* dcts_strerror(int code) {
+  switch (code) {
+    case DCTS_OK: return "ok";
+    case DCTS_E_NULL: return "required pointer is NULL";
+    case DCTS_E_SHAPE: return "bad shape (N, C, H, W must be > 0 and tile edges <= 512)";
+    case DCTS_E_CHANNELS: return "channel slice outside [0, C_total)";
+    case DCTS_E_STRIDE: return "rows must be dense: strideW == 1 and strideH >= W";
+    case DCTS_E_WORKSPACE: return "workspace missing or smaller than dcts_workspace_bytes()";
+    case DCTS_E_UNSUPPORTED: return "no kernel of the requested family for this shape";
+    case DCTS_E_ALIGN: return "pointer not 4-byte aligned";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "unknown dctscore error";
+}
+
+size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W) {
+  if (N <= 0 || C_count <= 0 || H <= 0 || W <= 0) return 0;
+  // worst case: odd front pad taken, direct kernel used
+  const int64_t HP = H + 1, WP = W + 1;
+  return direct_ws(N * C_count, (int)HP, (int)WP).total;
+}
+
+int dcts_has_codelet(int64_t H, int64_t W) { return has_codelet(H, W) ? 1 : 0; }
+
+int dcts_energy_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                       int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                       int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd,
+                       float* out_nc, void* workspace, size_t workspace_bytes, void* stream,
+                       int32_t algo) {
+  return run<false>(x, N, C_total, H, W, strideN, strideC, strideH, strideW, c_begin, c_count,
+                    pad_front_if_odd, out_nc, workspace, workspace_bytes, stream, algo);
+}
+
+int dcts_energy_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                    int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                    int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd, float* out_nc,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+  return run<false>(x, N, C_total, H, W, strideN, strideC, strideH, strideW, c_begin, c_count,
+                    pad_front_if_odd, out_nc, workspace, workspace_bytes, stream, DCTS_ALGO_AUTO);
+}
+
+int dcts_dct2d_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                      int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                      int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd,
+                      float* out_coeff, void* workspace, size_t workspace_bytes, void* stream,
+                      int32_t algo) {
+  return run<true>(x, N, C_total, H, W, strideN, strideC, strideH, strideW, c_begin, c_count,
+                   pad_front_if_odd, out_coeff, workspace, workspace_bytes, stream, algo);
+}
+
+int dcts_dct2d_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                   int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                   int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd, float* out_coeff,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  return run<true>(x, N, C_total, H, W, strideN, strideC, strideH, strideW, c_begin, c_count,
+                   pad_front_if_odd, out_coeff, workspace, workspace_bytes, stream, DCTS_ALGO_AUTO);
+}
+
+int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float* out_c,
+                       void* stream) {
+  if (!energy_nc || !out_c) return DCTS_E_NULL;
+  if (N <= 0 || C_count <= 0) return DCTS_E_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_batch_sum, dim3((unsigned)((C_count + 255) / 256)), dim3(256), 0, st,
+                     energy_nc, (long long)N, (long long)C_count, out_c);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+"""Operator-level seam: the tensor -> per-map energy call that replaces the reference's
+Python list comprehension over maps (utils/common.py:265-270, :283-287, :299-303)."""
+import torch
+
+from . import _lib
+
+ALGO_AUTO, ALGO_DIRECT, ALGO_CODELET = 0, 1, 2
+
+# one scratch buffer per (device, stream); grown on demand, reused across calls
+_workspaces = {}
+
+
+def _workspace(device, stream_ptr, nbytes):
+    key = (device.index, stream_ptr)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def _check_input(x):
+    if not isinstance(x, torch.Tensor):
+        raise TypeError("expected a torch.Tensor")
+    if x.dim() != 4:
+        raise ValueError("expected [N, C, H, W], got shape %s" % (tuple(x.shape),))
+    if x.dtype != torch.float32:
+        raise TypeError("feature maps must be float32 (the reference path is fp32), got %s" % x.dtype)
+    if not x.is_cuda:
+        raise RuntimeError(
+            "dct_pruning_amd runs on the GPU only: got a %s tensor. There is no CPU fallback; "
+            "the CPU restatement under oracle/ is test infrastructure." % x.device)
+
+
+def _slice(x, c_begin, c_count):
+    C = x.shape[1]
+    if c_count is None:
+        c_count = C - c_begin
+    return int(c_begin), int(c_count)
+
+
+def has_codelet(H, W):
+    return bool(_lib.load().dcts_has_codelet(H, W))
+
+
+def _call(fn_name, x, c_begin, c_count, pad_front_if_odd, out, algo):
+    lib = _lib.load()
+    N, C, H, W = x.shape
+    if x.stride(3) != 1 or x.stride(2) < W:
+        x = x.contiguous()
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    nbytes = lib.dcts_workspace_bytes(N, c_count, H, W)
+    ws = _workspace(x.device, stream, nbytes)
+    with torch.cuda.device(x.device):
+        code = getattr(lib, fn_name)(
+            x.data_ptr(), N, C, H, W, x.stride(0), x.stride(1), x.stride(2), x.stride(3),
+            c_begin, c_count, 1 if pad_front_if_odd else 0, out.data_ptr(),
+            ws.data_ptr(), ws.numel(), stream, algo)
+    _lib.check(code)
+    return out
+
+
+def energy_nc(x, c_begin=0, c_count=None, pad_front_if_odd=False, algo=ALGO_AUTO, out=None):
+    """E[n, j] = sum_{u,v} dct_2d(x[n, c_begin+j], norm='ortho')[u,v]**2  -> [N, c_count] fp32.
+
+    pad_front_if_odd=True reproduces torch2dct (utils/common.py:230-239): an odd-H map gets
+    one zero row and one zero column in front before the transform.
+    Enqueues on the current stream of x's device; no synchronisation.
+    """
+    _check_input(x)
+    c_begin, c_count = _slice(x, c_begin, c_count)
+    N = x.shape[0]
+    if out is None:
+        out = torch.empty((N, c_count), dtype=torch.float32, device=x.device)
+    elif out.shape != (N, c_count) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("out must be a contiguous float32 [N, c_count] tensor on x's device")
+    return _call("dcts_energy_f32_ex", x, c_begin, c_count, pad_front_if_odd, out, algo)
+
+
+def dct2d(x, c_begin=0, c_count=None, pad_front_if_odd=False, algo=ALGO_AUTO):
+    """Orthonormal 2-D DCT-II coefficients of every map -> [N, c_count, H', W'] fp32."""
+    _check_input(x)
+    c_begin, c_count = _slice(x, c_begin, c_count)
+    N, _, H, W = x.shape
+    pad = 1 if (pad_front_if_odd and H % 2 == 1) else 0
+    out = torch.empty((N, c_count, H + pad, W + pad), dtype=torch.float32, device=x.device)
+    return _call("dcts_dct2d_f32_ex", x, c_begin, c_count, pad_front_if_odd, out, algo)
+
+
+def batch_sum(energy):
+    """out[j] = sum_n energy[n, j], n ascending (fused variant for the bench / single-sweep mode)."""
+    if energy.dim() != 2 or energy.dtype != torch.float32 or not energy.is_cuda:
+        raise ValueError("expected a float32 CUDA tensor [N, C]")
+    energy = energy.contiguous()
+    out = torch.empty((energy.shape[1],), dtype=torch.float32, device=energy.device)
+    stream = torch.cuda.current_stream(energy.device).cuda_stream
+    with torch.cuda.device(energy.device):
+        _lib.check(_lib.load().dcts_batch_sum_f32(energy.data_ptr(), energy.shape[0], energy.shape[1],
+                                                  out.data_ptr(), stream))
+    return out

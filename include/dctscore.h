@@ -1,0 +1,138 @@
+/*
+ * dctscore.h — C ABI of libdctscore.so, the MI355X (gfx950) implementation of the
+ * DCT importance-score hot path of semchan/DCT_Pruning.
+ *
+ * The reference has no native code: the seam this library cuts at is the Python
+ * block  utils/common.py:265-274  (get_feature_hook), :283-291 (densenet hook) and
+ * :299-307 (u2net input hook):
+ *
+ *     c = [dct.dct_2d(output[i,j,:,:], norm='ortho') for i in range(a) for j in range(b)]
+ *     c = cnt_score(c)            # per map: sum(coeff * coeff)      (utils/common.py:249-255)
+ *     c = c.view(a, -1)           # [N, C] per-map energies
+ *
+ * i.e. "feature-map tensor on the device -> one fp32 energy per (sample, channel)".
+ * Everything after that (sum over the batch, running mean, np.save) stays on the host in
+ * Python exactly as the reference does it (utils/common.py:271-277).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (hipMalloc'd / torch CUDA tensors). The caller owns
+ *     every buffer; the library allocates nothing and keeps no state besides immutable
+ *     kernel code.
+ *   - Strides are in ELEMENTS (floats), as torch.Tensor.stride() reports them.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Every entry
+ *     point only ENQUEUES work on that stream; there is no implicit synchronisation.
+ *   - Return value: 0 = ok; negative = DCTS_E_* (bad argument / unsupported shape);
+ *     positive = a hipError_t raised by the launch. Nothing throws, aborts or prints.
+ *   - Re-entrant and thread-safe; safe to call with the Python GIL released.
+ */
+#ifndef DCTSCORE_H_
+#define DCTSCORE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCTS_ABI_VERSION 1
+
+enum {
+  DCTS_OK = 0,
+  DCTS_E_NULL = -1,        /* a required pointer is NULL                                */
+  DCTS_E_SHAPE = -2,       /* N, C, H or W <= 0, or H/W beyond DCTS_MAX_EDGE            */
+  DCTS_E_CHANNELS = -3,    /* [c_begin, c_begin + c_count) not inside [0, C_total)      */
+  DCTS_E_STRIDE = -4,      /* innermost stride != 1 or row stride < W (rows must be dense) */
+  DCTS_E_WORKSPACE = -5,   /* workspace smaller than dcts_workspace_bytes() reports     */
+  DCTS_E_UNSUPPORTED = -6, /* combination not implemented (see dcts_strerror)           */
+  DCTS_E_ALIGN = -7        /* pointer not 4-byte aligned                                */
+};
+
+/* Largest tile edge (after the optional odd front pad) any kernel accepts. */
+#define DCTS_MAX_EDGE 512
+
+/* Kernel family selector for dcts_energy_f32_ex (testing / benchmarking). */
+enum {
+  DCTS_ALGO_AUTO = 0,     /* pick the fastest kernel that supports the shape                     */
+  DCTS_ALGO_DIRECT = 1,   /* cosine-basis-in-LDS separable kernel, any (H, W) <= DCTS_MAX_EDGE   */
+  DCTS_ALGO_CODELET = 2   /* register-resident factorised DCT codelets (selected tile sizes)     */
+};
+
+/* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */
+int dcts_version(void);
+
+/* Human-readable text for a return code of this library (never NULL). */
+const char* dcts_strerror(int code);
+
+/*
+ * Scratch bytes dcts_energy_f32 needs for a call with these sizes (may be 0). The caller
+ * allocates it once and may reuse it across calls on the same stream.
+ */
+size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W);
+
+/*
+ * Per-map DCT energy.  Replaces utils/common.py:267 + :249-255 (and :285 / :301 through
+ * torch2dct, :230-239, when pad_front_if_odd != 0).
+ *
+ *   x            fp32 feature maps, logical shape [N, C_total, H, W]; element (n,c,h,w) is at
+ *                x[n*strideN + c*strideC + h*strideH + w*strideW]; strideW must be 1.
+ *   c_begin,
+ *   c_count      channel slice to score (densenet hook: c_begin = C_total-12, c_count = 12).
+ *   pad_front_if_odd
+ *                0: transform the H x W map as is (torch_dct path).
+ *                1: cv2 path of torch2dct — if H is odd, one zero row is put in front of the
+ *                   rows AND one zero column in front of the columns before the transform
+ *                   (np.pad(t,(1,0)) pads every axis; the test is on H only).
+ *   out_nc       [N, c_count] fp32, row-major:
+ *                out_nc[n*c_count + j] = sum_{u,v} DCT2_ortho(x[n, c_begin+j])[u,v]^2
+ *   workspace    >= dcts_workspace_bytes(N, c_count, H, W) bytes of device memory, or NULL
+ *                when that is 0.
+ */
+int dcts_energy_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                    int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                    int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd,
+                    float* out_nc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same, with an explicit kernel family (DCTS_ALGO_*). DCTS_E_UNSUPPORTED if that family
+ * has no kernel for the shape. */
+int dcts_energy_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                       int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                       int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd,
+                       float* out_nc, void* workspace, size_t workspace_bytes, void* stream,
+                       int32_t algo);
+
+/* 1 if DCTS_ALGO_CODELET has a kernel for an (H, W) tile (sizes AFTER the odd pad). */
+int dcts_has_codelet(int64_t H, int64_t W);
+
+/*
+ * Full coefficient output (parity/debug and the coefficient-domain API the reference's
+ * commented-out variants hint at, utils/common.py:268-269). Same addressing as above;
+ *   out_coeff    [N, c_count, H', W'] fp32 dense, H' = H + (pad && H odd), W' likewise;
+ *                out_coeff[n,j] = dct_2d(x[n, c_begin+j], norm='ortho').
+ *   workspace    as for dcts_energy_f32 (same size query).
+ */
+int dcts_dct2d_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                   int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                   int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd,
+                   float* out_coeff, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same, with an explicit kernel family (DCTS_ALGO_*). */
+int dcts_dct2d_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                      int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                      int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd,
+                      float* out_coeff, void* workspace, size_t workspace_bytes, void* stream,
+                      int32_t algo);
+
+/*
+ * Fused batch reduction for benchmarking and for the single-sweep harness:
+ *   out_c[j] = sum_n energy[n, j]   (fp32, fixed summation order n = 0..N-1, so the result
+ *   is bit-identical to torch's  c.view(a,-1).sum(0)  only up to summation order; the
+ *   reference-exact path is dcts_energy_f32 + host-side sum(0), utils/common.py:271-274).
+ */
+int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float* out_c,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTSCORE_H_ */

@@ -1,0 +1,57 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/dctscore.h declares;
+argument validation paths that never launch a kernel return the documented codes."""
+import ctypes
+import os
+import re
+
+from dct_pruning_amd import _lib
+
+
+def _declared_functions(root):
+    text = open(os.path.join(root, "include", "dctscore.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(repo_root):
+    declared = _declared_functions(repo_root)
+    assert declared, "no prototypes found in include/dctscore.h"
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_library_exports_every_symbol(repo_root):
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared_functions(repo_root):
+        assert hasattr(lib, name), name
+
+
+def test_version_and_strerror():
+    lib = _lib.load()
+    assert lib.dcts_version() == _lib.ABI_VERSION
+    assert lib.dcts_strerror(0) == b"ok"
+    for code in range(-7, 0):
+        assert lib.dcts_strerror(code)
+    assert lib.dcts_strerror(-99) == b"unknown dctscore error"
+
+
+def test_workspace_query_and_codelet_table():
+    lib = _lib.load()
+    assert lib.dcts_workspace_bytes(0, 1, 8, 8) == 0
+    assert lib.dcts_workspace_bytes(4, 4, 8, 8) > 0
+    for n in (2, 4, 7, 8, 9, 10, 14, 16, 18, 20, 28, 32, 36, 40, 56, 64):
+        assert lib.dcts_has_codelet(n, n) == 1
+    assert lib.dcts_has_codelet(57, 57) == 0 and lib.dcts_has_codelet(8, 16) == 0
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    fake = 0x1000  # never dereferenced: every case fails validation before any launch
+
+    def call(x=fake, n=1, c=4, h=8, w=8, sn=256, sc=64, sh=8, sw=1, cb=0, cc=4, out=fake):
+        return lib.dcts_energy_f32(x, n, c, h, w, sn, sc, sh, sw, cb, cc, 0, out, None, 0, None)
+
+    assert call(x=None) == -1 and call(out=None) == -1
+    assert call(h=0) == -2 and call(h=513, w=513, sh=513) == -2
+    assert call(cb=2, cc=3) == -3 and call(cc=0) == -3
+    assert call(sw=2) == -4 and call(sh=4) == -4
+    assert call(x=0x1001) == -7
