@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""bench.py — DCT+score throughput of the hot path on synthetic ResNet-50 feature maps.
+
+Workload (BASELINE.json configs[3], the one the metric's 1/2/4/8-GPU figures are quoted on):
+the 49 hooked tensors of imp_score for resnet_50 (utils/common.py:557-607; shapes in
+dct_pruning_amd/schedules.py) at batch 256, fp32, synthetic, resident in HBM
+before the clock starts. One STEP = one batch pass of the hot path: for every hooked tensor
+one DCT+energy launch ([N,C,H,W] -> [N,C]) and one fused batch-sum/running-mean launch
+(utils/common.py:265-277). After the K timed steps (= `--limit K` batches) multi-GPU runs do
+the path's single exchange: one RCCL all-gather of the flat score buffer; it is inside the
+timed region.
+
+N > 1: layer/channel-range units are LPT-sharded over the ranks (dct_pruning_amd/sharding.py);
+total work is fixed, so scaling = "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+dominant kernel (the 56x56 codelet kernel, measured with HIP events on the launch stream
+inside the timed region) and `cpu_baseline` (the oracle's per-map loop on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+CFG_ID = 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--net", default="resnet_50")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-headline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def synth(n, c, h, w, seed, device):
+    """relu(randn) * exp(0.5 randn) per channel, channels c % 8 == 5 dead."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn(n, c, h, w, generator=g, device=device)
+    x.relu_()
+    s = torch.exp(0.5 * torch.randn(c, generator=g, device=device))
+    s[torch.arange(c, device=device) % 8 == 5] = 0
+    x.mul_(s[None, :, None, None])
+    return x
+
+
+class BoundUnit:
+    """One work unit with its launches pre-bound (ctypes argument tuples built once)."""
+
+    def __init__(self, lib, x, pad, stream_ptr, ws):
+        n, c, h, w = x.shape
+        self.x = x
+        self.h = h
+        self.nmaps = n * c
+        self.bytes = self.nmaps * (4 * h * w + 4)  # algorithmic bytes, SURVEY.md §8(d)
+        self.energy = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        self.fr = torch.zeros(c, dtype=torch.float32, device=x.device)
+        self.total = 0.0
+        self.n = n
+        self._lib = lib
+        self._stream = stream_ptr
+        self._eargs = (x.data_ptr(), n, c, h, w, x.stride(0), x.stride(1), x.stride(2), x.stride(3),
+                       0, c, 1 if pad else 0, self.energy.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr)
+
+    def launch_energy(self):
+        rc = self._lib.dcts_energy_f32(*self._eargs)
+        if rc:
+            raise RuntimeError("dcts_energy_f32 -> %d" % rc)
+
+    def launch_update(self):
+        rc = self._lib.dcts_running_mean_update_f32(self.energy.data_ptr(), self.n, self.fr.numel(),
+                                                    self.fr.data_ptr(), self.total, self._stream)
+        if rc:
+            raise RuntimeError("dcts_running_mean_update_f32 -> %d" % rc)
+        self.total += self.n
+
+
+def cpu_baseline(points, seconds):
+    """The oracle's restatement of the reference loop (utils/common.py:265-277) on one sample's
+    worth of the same hooked tensors, single thread (the per-map loop is serial Python)."""
+    from oracle import dct_oracle as orc
+    from dct_pruning_amd import schedules
+
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(99)
+    tensors = []
+    for pt in points:
+        cb, cc, pad = schedules.scored_shape(pt)
+        tensors.append((torch.relu(torch.randn(1, cc, pt.H, pt.W, generator=g)), pt.kind))
+    maps = 0
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        for x, kind in tensors:
+            st = orc.HookState()
+            if kind == "full":
+                orc.get_feature_hook(st, x)
+            elif kind == "last12":
+                orc.get_feature_hook_densenet(st, x)
+            else:
+                orc.get_feature_hook_u2net_input(st, (x,))
+            maps += x.shape[0] * x.shape[1]
+        reps += 1
+        if time.perf_counter() - t0 >= seconds or reps >= 8:
+            break
+    dt = time.perf_counter() - t0
+    # best-effort CPU: one batched FFT-DCT over all maps of a tensor, all cores
+    torch.set_num_threads(os.cpu_count() or 1)
+    t1 = time.perf_counter()
+    bmaps = 0
+    for x, kind in tensors:
+        orc.energy_nc_batched(x.expand(8, -1, -1, -1).contiguous(), pad_front_if_odd=(kind != "full"))
+        bmaps += 8 * x.shape[1]
+    dtb = time.perf_counter() - t1
+    return {
+        "value": maps / dt / 1e6, "unit": "Mmaps/s", "cores": 1, "kind": "port",
+        "sample": "%d x (1 sample of the %d hooked tensors = %d maps), per-map loop of "
+                  "oracle.get_feature_hook, torch CPU 1 thread, %.1f s" % (reps, len(tensors), maps // reps, dt),
+        "batched_all_cores": {"value": bmaps / dtb / 1e6, "unit": "Mmaps/s", "cores": os.cpu_count(),
+                              "sample": "8 samples per tensor, one batched FFT-DCT per tensor"},
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def headline(lib, dev, stream_ptr, ws_fn):
+    """SURVEY.md §8(d) headline micro-benchmarks: (N*C = 16384, 56x56) and (4096, 224x224);
+    buffers rotated so the working set exceeds L2 + Infinity Cache."""
+    out = {}
+    for name, nmaps, h, nbuf in [("56x56", 16384, 56, 3), ("224x224", 4096, 224, 1), ("28x28", 65536, 28, 3),
+                                 ("14x14", 262144, 14, 3), ("7x7", 1048576, 7, 3), ("32x32", 65536, 32, 3)]:
+        bufs = [synth(1, nmaps, h, h, 777 + i, dev) for i in range(nbuf)]
+        ws = ws_fn(1, nmaps, h, h)
+        units = [BoundUnit(lib, b, False, stream_ptr, ws) for b in bufs]
+        for u in units:
+            u.launch_energy()
+        torch.cuda.synchronize(dev)
+        reps = 30 if h < 224 else 10
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for i in range(reps):
+            ev[i][0].record()
+            units[i % nbuf].launch_energy()
+            ev[i][1].record()
+        torch.cuda.synchronize(dev)
+        ts = sorted(a.elapsed_time(b) for a, b in ev)
+        med = ts[len(ts) // 2]
+        by = units[0].bytes
+        out[name] = {"maps": nmaps, "median_us": med * 1e3, "min_us": ts[0] * 1e3,
+                     "Mmaps_s": nmaps / med / 1e3, "GB_s": by / med / 1e6, "frac": by / med / 1e6 / HBM_PEAK_GBS}
+        del units, bufs
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback in the product path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dct_pruning_amd import _lib, schedules, sharding
+    from dct_pruning_amd.ops import _workspace
+    lib = _lib.load()
+    stream_ptr = torch.cuda.current_stream(dev).cuda_stream
+
+    def ws_fn(n, c, h, w):
+        return _workspace(dev, stream_ptr, lib.dcts_workspace_bytes(n, c, h, w))
+
+    points = schedules.SCHEDULES[args.net]()
+    N = args.batch
+    scored = [schedules.scored_shape(p) for p in points]
+    chans = [s[1] for s in scored]
+    cost_pc = [float(N * (4 * p.H * p.W + 4)) for p in points]
+    total_cost = sum(c * k for c, k in zip(chans, cost_pc))
+    units = sharding.make_units(chans, cost_pc, max_unit_cost=(total_cost / (world * 6)) if world > 1 else None)
+    owner, load = sharding.assign(units, world)
+    off, seg = sharding.layout(units, owner, world)
+
+    mine = [i for i in range(len(units)) if owner[i] == rank]
+    bound = []
+    for i in mine:
+        u = units[i]
+        p = points[u.layer]
+        x = synth(N, u.c_hi - u.c_lo, p.H, p.W, 20260104 + 1000 * CFG_ID + 64 * u.layer + (u.c_lo % 61), dev)
+        bound.append((i, BoundUnit(lib, x, scored[u.layer][2], stream_ptr, ws_fn(N, u.c_hi - u.c_lo, p.H, p.W))))
+    maps_per_step = N * sum(chans)
+
+    # dominant kernel: the one owning the most algorithmic bytes on this rank
+    by_edge = {}
+    for _, b in bound:
+        by_edge[b.h] = by_edge.get(b.h, 0) + b.bytes
+    dom_edge = max(by_edge, key=by_edge.get)
+    dom = [b for _, b in bound if b.h == dom_edge]
+
+    def step(events=None):
+        for _, b in bound:
+            if events is not None and b.h == dom_edge:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                b.launch_energy()
+                e1.record()
+                events.append((e0, e1, b.bytes))
+            else:
+                b.launch_energy()
+            b.launch_update()
+
+    def gather():
+        flat = torch.zeros(seg, dtype=torch.float32, device=dev)
+        for i, b in bound:
+            flat[off[i]:off[i] + b.fr.numel()] = b.fr
+        return sharding.all_gather_scores(flat, world)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        gather()
+    for _, b in bound:
+        b.fr.zero_()
+        b.total = 0.0
+
+    events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    gathered = gather()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    # sanity on the result the timed region produced: Parseval against the inputs (device-side)
+    i0, b0 = bound[0]
+    ref = (b0.x.double() ** 2).sum(dim=(-2, -1)).mean(0)
+    got = gathered[rank, off[i0]:off[i0] + b0.fr.numel()].double()
+    rel = ((got - ref).abs() / ref.clamp_min(1e-30))[ref > 0].max().item()
+    if not rel <= 1e-4:
+        sys.exit("bench sanity check failed: rel err %g" % rel)
+
+    dom_ms = sum(a.elapsed_time(b) for a, b, _ in events)
+    dom_bytes = sum(by for _, _, by in events)
+    n_launch = max(len(events), 1)
+
+    if rank == 0:
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_energy_codelet_%d" % dom_edge, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "feature-map DCT+score throughput", "value": maps_per_step * args.steps / dt / 1e6,
+            "unit": "Mmaps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s hooked feature maps (49 tensors, %d maps/sample: 56x56 x1344, 28x28 x3200, "
+                                   "14x14 x9472, 7x7 x8704), batch %d, limit=steps" % (args.net, sum(chans), N),
+                       "global_batch": N, "sharding": "layer/channel-range units, LPT, 1 all-gather" if world > 1 else "none",
+                       "units_rank0": len(bound), "load_imbalance": (max(load) / (sum(load) / world)) if world > 1 else 1.0},
+            "GB_s_whole_step": total_cost * args.steps / dt / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "k_energy_codelet<%d,%d>" % (dom_edge, dom_edge),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "launches": len(events), "avg_launch_us": dom_ms / n_launch * 1e3,
+                         "alg_bytes_per_launch": dom_bytes / n_launch},
+            "parity_check_rel_err": rel,
+        }
+        if not args.no_headline and world == 1:
+            res["headline"] = headline(lib, dev, stream_ptr, ws_fn)
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(points, args.cpu_seconds)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""Score accumulation: the reference's module globals feature_result / total
+(utils/common.py:258-259) and their update rule (:271-277), as objects.
+
+HostAccumulator   reference-exact: per-map energies come back to the host and the SAME torch
+                  CPU ops as the reference run on them (view/sum(0), three-rounding mean).
+DeviceAccumulator the fused device form (dcts_running_mean_update_f32): nothing leaves the
+                  GPU until the scores are read; same rounding sequence, batch sum in
+                  ascending n instead of torch's pairwise sum(0).
+"""
+import torch
+
+from . import _lib
+
+
+class HostAccumulator:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        # utils/common.py:380-381
+        self.feature_result = torch.tensor(0.)
+        self.total = torch.tensor(0.)
+
+    def update(self, energy_nc):
+        """energy_nc: [a, b] fp32 (any device). utils/common.py:271-277."""
+        a = energy_nc.shape[0]
+        c = energy_nc.detach().to("cpu", torch.float32)
+        c = c.view(a, -1)
+        c = c.sum(0)
+        self.feature_result = self.feature_result * self.total + c
+        self.total = self.total + a
+        self.feature_result = self.feature_result / self.total
+
+    def scores(self):
+        return self.feature_result.numpy()
+
+
+class DeviceAccumulator:
+    def __init__(self, c_count, device):
+        self.device = torch.device(device)
+        self.feature_result = torch.zeros(c_count, dtype=torch.float32, device=self.device)
+        self.total = 0.0
+
+    def reset(self):
+        self.feature_result.zero_()
+        self.total = 0.0
+
+    def update(self, energy_nc):
+        if energy_nc.dim() != 2 or energy_nc.shape[1] != self.feature_result.numel():
+            raise ValueError("expected [N, %d] energies" % self.feature_result.numel())
+        e = energy_nc.contiguous()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().dcts_running_mean_update_f32(
+                e.data_ptr(), e.shape[0], e.shape[1], self.feature_result.data_ptr(), float(self.total), stream))
+        self.total += e.shape[0]
+
+    def scores(self):
+        return self.feature_result.cpu().numpy()

@@ -279,14 +279,60 @@ __global__ __launch_bounds__(kDirectThreads) void k_energy_direct(
   }
 }
 
-// out_c[j] = sum_n e[n*C + j], n ascending
-__global__ void k_batch_sum(const float* __restrict__ e, long long N, long long C,
-                            float* __restrict__ out_c) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= C) return;
+// Batch sum over n of E[n][j] for a 32-channel strip per block: 8 n-slices run in parallel
+// (slice s takes n = s, s+8, ...), partials are combined in slice order -> a fixed,
+// launch-independent summation order (bit-reproducible, no atomics).
+constexpr int kSumCh = 32, kSumSl = 16;
+__device__ __forceinline__ float strip_batch_sum(const float* __restrict__ e, long long N,
+                                                 long long C, long long j, int slice,
+                                                 float (*part)[kSumCh]) {
   float s = 0.f;
-  for (long long n = 0; n < N; ++n) s += e[n * C + j];
-  out_c[j] = s;
+  if (j < C) {
+    long long n = slice;
+#pragma unroll 1
+    for (; n + 3 * kSumSl < N; n += 4 * kSumSl) {
+      const float a0 = e[n * C + j], a1 = e[(n + kSumSl) * C + j];
+      const float a2 = e[(n + 2 * kSumSl) * C + j], a3 = e[(n + 3 * kSumSl) * C + j];
+      s += a0;
+      s += a1;
+      s += a2;
+      s += a3;
+    }
+    for (; n < N; n += kSumSl) s += e[n * C + j];
+  }
+  part[slice][threadIdx.x % kSumCh] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (slice == 0) {
+#pragma unroll
+    for (int i = 0; i < kSumSl; ++i) t += part[i][threadIdx.x % kSumCh];
+  }
+  return t;  // valid in slice 0
+}
+
+// out_c[j] = sum_n e[n*C + j]
+__global__ __launch_bounds__(kSumCh * kSumSl) void k_batch_sum(const float* __restrict__ e, long long N,
+                                                               long long C, float* __restrict__ out_c) {
+  __shared__ float part[kSumSl][kSumCh];
+  const int slice = threadIdx.x / kSumCh;
+  const long long j = (long long)blockIdx.x * kSumCh + threadIdx.x % kSumCh;
+  const float t = strip_batch_sum(e, N, C, j, slice, part);
+  if (slice == 0 && j < C) out_c[j] = t;
+}
+
+// fr[j] <- (fr[j] * total + sum_n e[n*C + j]) / (total + N): the running-mean update of
+// utils/common.py:274-277 fused with the batch sum of :273 (same three fp32 roundings)
+__global__ __launch_bounds__(kSumCh * kSumSl) void k_running_mean(const float* __restrict__ e, long long N,
+                                                                  long long C, float* __restrict__ fr,
+                                                                  float total) {
+  __shared__ float part[kSumSl][kSumCh];
+  const int slice = threadIdx.x / kSumCh;
+  const long long j = (long long)blockIdx.x * kSumCh + threadIdx.x % kSumCh;
+  const float t = strip_batch_sum(e, N, C, j, slice, part);
+  if (slice == 0 && j < C) {
+    const float acc = __fadd_rn(__fmul_rn(fr[j], total), t);
+    fr[j] = __fdiv_rn(acc, __fadd_rn(total, float(N)));
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -472,8 +518,18 @@ int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float
   if (!energy_nc || !out_c) return DCTS_E_NULL;
   if (N <= 0 || C_count <= 0) return DCTS_E_SHAPE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(k_batch_sum, dim3((unsigned)((C_count + 255) / 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(k_batch_sum, dim3((unsigned)((C_count + kSumCh - 1) / kSumCh)), dim3(kSumCh * kSumSl), 0, st,
                      energy_nc, (long long)N, (long long)C_count, out_c);
+  return (int)hipGetLastError();
+}
+
+int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_count,
+                                 float* feature_result, float total_before, void* stream) {
+  if (!energy_nc || !feature_result) return DCTS_E_NULL;
+  if (N <= 0 || C_count <= 0) return DCTS_E_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(k_running_mean, dim3((unsigned)((C_count + kSumCh - 1) / kSumCh)), dim3(kSumCh * kSumSl), 0, st,
+                     energy_nc, (long long)N, (long long)C_count, feature_result, total_before);
   return (int)hipGetLastError();
 }
 

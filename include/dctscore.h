@@ -132,6 +132,18 @@ int dcts_dct2d_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int
 int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float* out_c,
                        void* stream);
 
+/*
+ * Device-side form of the running-mean update of get_feature_hook, utils/common.py:273-277:
+ *   c = sum_n energy_nc[n, :]
+ *   feature_result = (feature_result * total_before + c) / (total_before + N)
+ * feature_result is [C_count] fp32 in/out on the device (zeros before the first batch, like
+ * the reference's torch.tensor(0.) broadcast); the caller keeps `total` on the host and
+ * adds N after each call. Same three fp32 roundings as the reference (no FMA contraction);
+ * the batch sum runs n = 0..N-1 in order.
+ */
+int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_count,
+                                 float* feature_result, float total_before, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,3 +166,21 @@ def test_errors_are_loud():
         dpa.energy_nc(torch.zeros(1, 4, 8, 8).cuda(), c_begin=2, c_count=5)
     with pytest.raises(DctScoreError):
         dpa.energy_nc(torch.zeros(1, 1, 57, 57).cuda(), algo=dpa.ALGO_CODELET)
+
+
+def test_device_accumulator_matches_reference_rule():
+    """dcts_running_mean_update_f32 vs the reference's host-side update (utils/common.py:271-277)."""
+    from dct_pruning_amd.accumulate import DeviceAccumulator, HostAccumulator
+    host, dev = HostAccumulator(), DeviceAccumulator(37, "cuda:0")
+    st = orc.HookState()
+    for i, n in enumerate([5, 256, 3]):
+        x = synth(n, 37, 8, 8, 300 + i)
+        e = dpa.energy_nc(x.cuda())
+        host.update(e)
+        dev.update(e)
+        orc.get_feature_hook(st, x)
+    assert host.total.item() == dev.total == 264
+    np.testing.assert_allclose(dev.scores(), host.scores(), rtol=2e-6)
+    np.testing.assert_allclose(host.scores(), st.feature_result.numpy(), rtol=RTOL)
+    dead = np.arange(37) % 8 == 5
+    assert (dev.scores()[dead] == 0).all() and (host.scores()[dead] == 0).all()
