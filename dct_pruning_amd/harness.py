@@ -1,0 +1,256 @@
+"""Host-side mirror of the reference's hook / imp_score interface (utils/common.py:258-977).
+
+Same entry points, same argument meaning, same side effects:
+  get_feature_hook / get_feature_hook_densenet / get_feature_hook_u2net_input
+      forward-hook callables `(module, input, output) -> None` updating the module-level
+      accumulator (the reference's globals feature_result / total, utils/common.py:258-259);
+  inference / u2netp_inference   (utils/common.py:312-332);
+  imp_score(net, args)           (utils/common.py:367-977): creates
+      importance_score/<net>_limit<L>/ under the CWD, runs one forward sweep of `limit`
+      batches per hook point, np.save()s the (C,) fp32 vectors under the reference's file
+      names and prints the reference's progress lines.
+What changed underneath: the per-map Python loop over dct_2d + .item() is ONE
+dcts_energy_f32 launch per hooked tensor (ops.energy_nc), and the hooked tensor never
+leaves the GPU.
+
+Additions (opt-in, results identical on fixed batches):
+  single_sweep=True   all hook points registered at once, one sweep instead of 12..118
+                      (SURVEY.md §8 f1);
+  accumulate="device" running mean kept on the GPU (dcts_running_mean_update_f32);
+  world_size > 1      hook points LPT-sharded over ranks, one all-gather at the end,
+                      rank 0 writes the files.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import ops, schedules, sharding
+from .accumulate import DeviceAccumulator, HostAccumulator
+
+# tests swap this for the oracle to exercise the host logic without a GPU
+_energy_nc = ops.energy_nc
+
+# the reference's module globals (utils/common.py:258-259)
+_acc = HostAccumulator()
+
+
+def _scored_tensor(kind, inputs, output):
+    return inputs[0] if kind == "input" else output
+
+
+def _hook_energy(kind, x):
+    b = x.shape[1]
+    if kind == "last12":
+        return _energy_nc(x, c_begin=b - 12, c_count=12, pad_front_if_odd=True)
+    if kind == "input":
+        return _energy_nc(x, pad_front_if_odd=True)
+    return _energy_nc(x)
+
+
+def get_feature_hook(self, input, output):
+    """utils/common.py:262-277."""
+    _acc.update(_hook_energy("full", output))
+
+
+def get_feature_hook_densenet(self, input, output):
+    """utils/common.py:280-293: channels [b-12, b), cv2 path."""
+    _acc.update(_hook_energy("last12", output))
+
+
+def get_feature_hook_u2net_input(self, input, output):
+    """utils/common.py:296-309: scores input[0], cv2 path."""
+    _acc.update(_hook_energy("input", input[0]))
+
+
+_HOOKS = {"full": get_feature_hook, "last12": get_feature_hook_densenet, "input": get_feature_hook_u2net_input}
+
+
+def _net_device(net):
+    for p in net.parameters():
+        return p.device
+    return torch.device("cpu")
+
+
+def inference(net, train_loader, limit):
+    """utils/common.py:312-320 (data goes to the net's device instead of an unconditional .cuda())."""
+    net.eval()
+    dev = _net_device(net)
+    for batch_idx, (data, _) in enumerate(train_loader):
+        if batch_idx >= limit:
+            break
+        data = data.to(dev)
+        with torch.no_grad():
+            net(data)
+
+
+def u2netp_inference(net, train_loader, limit):
+    """utils/common.py:323-332: dict batches with key 'image', cast to float."""
+    net.eval()
+    dev = _net_device(net)
+    with torch.no_grad():
+        for batch_idx, data in enumerate(train_loader):
+            if batch_idx >= limit:
+                break
+            inputs = data["image"].type(torch.FloatTensor)
+            net(inputs.to(dev))
+
+
+def _resolve(net, path):
+    """'features.2' -> net.features[2], 'layer1.0.relu1' -> net.layer1[0].relu1 (what the
+    reference's eval('net.' + name) / net.features[idx] expressions reach)."""
+    mod = net
+    for atom in path.split("."):
+        mod = mod[int(atom)] if atom.isdigit() else getattr(mod, atom)
+    return mod
+
+
+def _schedule_for(net, name):
+    if name == "googlenet":
+        return schedules.googlenet(getattr(net, "filters_p", None))
+    if name == "resnet_50":
+        return schedules.resnet_50(tuple(getattr(net, "num_blocks", (3, 4, 6, 3))))
+    if name not in schedules.SCHEDULES:
+        raise ValueError("imp_score: unknown net %r" % (name,))
+    return schedules.SCHEDULES[name]()
+
+
+def _done_line(net_name, idx, stem):
+    """The progress line the reference prints after saving (e.g. utils/common.py:395, :510, :515)."""
+    if net_name == "u2netp":
+        return None
+    if net_name == "googlenet":
+        if stem.endswith("_"):
+            return "/" + stem[:-1] + ":done!"
+        head, tp = stem.split("_", 2)[0:2], stem.split("_", 2)[2]
+        return "/" + "_".join(head) + tp + ":done!"
+    return "/" + stem + ":done!"
+
+
+def _save(out_dir, net_name, pt, scores):
+    for stem, lo, hi in pt.files:
+        arr = scores if lo is None else scores[lo:hi]
+        np.save(os.path.join(out_dir, stem + ".npy"), arr)
+        line = _done_line(net_name, 0, stem)
+        if line:
+            print(line)
+
+
+class _PointHook:
+    """A hook with its own accumulator (single-sweep / device modes)."""
+
+    def __init__(self, kind, accumulate, device):
+        self.kind, self.accumulate, self.device, self.acc = kind, accumulate, device, None
+
+    def __call__(self, module, inputs, output):
+        e = _hook_energy(self.kind, _scored_tensor(self.kind, inputs, output))
+        if self.acc is None:
+            self.acc = DeviceAccumulator(e.shape[1], e.device) if self.accumulate == "device" else HostAccumulator()
+        self.acc.update(e)
+
+    def scores(self):
+        return np.ascontiguousarray(self.acc.scores(), dtype=np.float32)
+
+
+def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host", group=None):
+    """Counterpart of utils/common.py:367-977. `args` needs .net, .limit (and whatever
+    load_data reads when train_loader is None)."""
+    global _acc
+    out_dir = "importance_score/" + args.net + "_limit" + str(args.limit)
+    world, rank = 1, 0
+    if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        world = torch.distributed.get_world_size(group)
+        rank = torch.distributed.get_rank(group)
+    if rank == 0:
+        if not os.path.isdir("importance_score"):
+            os.mkdir("importance_score")
+        if not os.path.isdir(out_dir):
+            os.mkdir(out_dir)
+
+    print("==> Loading data of {}..".format(getattr(args, "dataset", "synthetic")))
+    if train_loader is None:
+        from .data import load_data
+        train_loader, _ = load_data(args)
+
+    print("==> Generating importance score..")
+    print("Importance Score is located at ./" + out_dir)
+    _acc = HostAccumulator()
+
+    pts = _schedule_for(net, args.net)
+    sweep = u2netp_inference if args.net == "u2netp" else inference
+    dev = _net_device(net)
+
+    # which hook points are mine (all of them on one GPU)
+    if world > 1:
+        units = sharding.make_units([1] * len(pts), [float(p.C * p.H * p.W) for p in pts])
+        owner, _ = sharding.assign(units, world)
+    else:
+        owner = [0] * len(pts)
+    mine = [i for i in range(len(pts)) if owner[i] == rank]
+    results = {}
+
+    if single_sweep:
+        hooks, handles = {}, []
+        for i in mine:
+            hooks[i] = _PointHook(pts[i].kind, accumulate, dev)
+            handles.append(_resolve(net, pts[i].module).register_forward_hook(hooks[i]))
+        sweep(net, train_loader, args.limit)
+        for h in handles:
+            h.remove()
+        for i in mine:
+            results[i] = hooks[i].scores()
+    else:
+        for i in mine:
+            pt = pts[i]
+            if args.net == "u2netp" and world == 1:
+                print("current layer:", "net." + pt.module)
+            layer = _resolve(net, pt.module)
+            if accumulate == "device":
+                hook = _PointHook(pt.kind, accumulate, dev)
+                handler = layer.register_forward_hook(hook)
+                sweep(net, train_loader, args.limit)
+                handler.remove()
+                results[i] = hook.scores()
+            else:
+                handler = layer.register_forward_hook(_HOOKS[pt.kind])
+                sweep(net, train_loader, args.limit)
+                handler.remove()
+                results[i] = np.ascontiguousarray(_acc.feature_result.numpy(), dtype=np.float32)
+                _acc.reset()
+            if world == 1:
+                _save(out_dir, args.net, pt, results[i])
+        if world == 1:
+            print("The importance score generation has been completed!")  # utils/common.py:977
+            return
+
+    if world > 1:
+        results = _gather_results(results, len(pts), owner, world, rank, dev, group)
+    if rank == 0:
+        for i, pt in enumerate(pts):
+            if args.net == "u2netp":
+                print("current layer:", "net." + pt.module)
+            _save(out_dir, args.net, pt, results[i])
+        print("The importance score generation has been completed!")
+    if world > 1:
+        torch.distributed.barrier(group)
+
+
+def _gather_results(local, n_layers, owner, world, rank, dev, group):
+    """One all-gather of the flat, equally padded score buffer (plus a tiny all-reduce that
+    tells every rank the channel counts, which only the owners know)."""
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    counts = torch.zeros(n_layers, dtype=torch.int64, device=cdev)
+    for i, v in local.items():
+        counts[i] = v.shape[0]
+    dist.all_reduce(counts, group=group)
+    counts = counts.cpu().tolist()
+    units = [sharding.Unit(i, 0, c, float(c)) for i, c in enumerate(counts)]
+    off, seg = sharding.layout(units, owner, world)
+    flat = torch.zeros(seg, dtype=torch.float32, device=cdev)
+    for i, v in local.items():
+        flat[off[i]:off[i] + counts[i]] = torch.from_numpy(v).to(cdev)
+    gathered = sharding.all_gather_scores(flat, world, group)
+    res = sharding.unpack(gathered, units, owner, off, counts)
+    return {i: r.cpu().numpy() for i, r in enumerate(res)}

@@ -59,9 +59,9 @@ def all_gather_scores(local_flat, world_size, group=None):
     if world_size == 1:
         return local_flat[None, :]
     import torch.distributed as dist
-    out = torch.empty((world_size, local_flat.numel()), dtype=local_flat.dtype, device=local_flat.device)
-    dist.all_gather_into_tensor(out, local_flat, group=group)
-    return out
+    out = torch.empty(world_size * local_flat.numel(), dtype=local_flat.dtype, device=local_flat.device)
+    dist.all_gather_into_tensor(out, local_flat.contiguous(), group=group)
+    return out.view(world_size, local_flat.numel())
 
 
 def unpack(gathered, units, owner, off, channel_counts):
