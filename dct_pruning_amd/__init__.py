@@ -10,10 +10,11 @@ from .ops import (  # noqa: F401
     ALGO_AUTO,
     ALGO_CODELET,
     ALGO_DIRECT,
+    ALGO_SPLIT,
     batch_sum,
     dct2d,
     energy_nc,
     has_codelet,
 )
 
-__all__ = ["energy_nc", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET"]
+__all__ = ["energy_nc", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT"]

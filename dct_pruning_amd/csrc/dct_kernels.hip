@@ -165,6 +165,159 @@ __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_cod
 }
 
 // ---------------------------------------------------------------------------------------
+// split-4 family: tiles whose edge N = 4*M is too long for one lane's registers
+// ---------------------------------------------------------------------------------------
+// A length-N DCT-II is cut by two radix-2 levels into four length-M problems ("roles"),
+// each run by one lane with an M-point codelet (dct_codelets.hpp recursion, top two levels
+// unrolled across waves instead of inside a lane). With x3 = x[N-1-p], x1 = x[2M-1-p],
+// x2 = x[2M+p], beta_p = (2p+1) pi / (8M):
+//   role 0: in[p] = (x[p] + x3) + (x1 + x2)                  DCT-II_M  -> X[4k]
+//   role 1: in[p] = (x[p] + x3) - (x1 + x2)                  DCT-IV_M  -> X[4k+2]
+//   role 2: in[p] =  (x[p] - x3) cos(beta) + (x1 - x2) sin(beta)            DCT-II_M -> A[k]
+//   role 3: in[p] = (-1)^p ((x1 - x2) cos(beta) - (x[p] - x3) sin(beta))    DCT-II_M -> B[k]
+// and the odd outputs are X[2(2j)+1] = A[j] + B[M-j], X[2(2j-1)+1] = A[j] - B[M-j] (0<j<M),
+// X[1] = A[0], X[2N-1...] = -B[0]. That last add/sub layer is a 45-degree rotation of each
+// pair scaled by sqrt(2); the energy kernels fuse it into the reduction,
+// (a+b)^2 + (a-b)^2 = 2a^2 + 2b^2, i.e. A[k], B[k] (k>0) are carried with weight sqrt(2).
+// Every other butterfly, rotation and twiddle of the transform is computed.
+//
+// k_pass1d transforms the row axis of In[b][n][line] (lines contiguous), one wave per
+// (64-line strip, role), the four role waves of a strip in one workgroup so they share the
+// strip's cache lines. Non-final pass: the result goes to T[b][line][role*M + k] through a
+// per-wave LDS transpose (coalesced stores), so the second launch of the same kernel
+// transforms the other axis. Final pass: squares are reduced per wave into partial sums.
+template <int M, int ROLE>
+__device__ __forceinline__ void split4_inputs(const float* __restrict__ col, long long rs,
+                                              float (&in)[M]) {
+  dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int p = decltype(i)::value;
+    const float x0 = col[(long long)p * rs];
+    const float x1 = col[(long long)(2 * M - 1 - p) * rs];
+    const float x2 = col[(long long)(2 * M + p) * rs];
+    const float x3 = col[(long long)(4 * M - 1 - p) * rs];
+    if constexpr (ROLE == 0) {
+      in[p] = (x0 + x3) + (x1 + x2);
+    } else if constexpr (ROLE == 1) {
+      in[p] = (x0 + x3) - (x1 + x2);
+    } else {
+      constexpr float c = float(dcts::cospi_frac(2 * p + 1, 8 * M));
+      constexpr float sn = float(dcts::sinpi_frac(2 * p + 1, 8 * M));
+      const float d1 = x0 - x3, d2 = x1 - x2;
+      if constexpr (ROLE == 2) {
+        in[p] = d1 * c + d2 * sn;
+      } else {
+        constexpr float sg = (p % 2 == 0) ? 1.f : -1.f;
+        in[p] = d2 * (sg * c) - d1 * (sg * sn);
+      }
+    }
+  });
+}
+
+template <int M, int ROLE>
+__device__ __forceinline__ void split4_transform(const float (&in)[M], float (&out)[M]) {
+  if constexpr (ROLE == 1)
+    dcts::Dct4<M>::run(in, out);
+  else
+    dcts::Dct2<M>::run(in, out);
+  if constexpr (ROLE == 0) out[0] *= dcts::kInvSqrt2;  // DC of the whole axis
+  if constexpr (ROLE >= 2) {
+    constexpr float r2 = float(1.41421356237309504880168872420969808);
+    dcts::static_for<M - 1>([&](auto i) DCTS_LAMBDA_INLINE { out[decltype(i)::value + 1] *= r2; });
+  }
+}
+
+template <int M>
+struct SplitCfg {
+  static constexpr int N = 4 * M;
+  static constexpr int STRIPS = (N + 63) / 64;
+  static constexpr int SW = (N + STRIPS - 1) / STRIPS;  // lines per strip (<= 64)
+  static constexpr int SWP = SW | 1;                    // odd LDS stride
+  static constexpr int WAVE_LDS = M * SWP;              // floats
+};
+
+template <int M, int ROLE, bool FINAL>
+__device__ __forceinline__ void split4_wave(const float* __restrict__ in_b, float* __restrict__ t_b,
+                                            float* my, int strip, int lane, float* part) {
+  using Cfg = SplitCfg<M>;
+  constexpr int N = Cfg::N, SW = Cfg::SW, SWP = Cfg::SWP;
+  const int line = strip * SW + lane;
+  const bool act = lane < SW && line < N;
+  float in[M], out[M];
+  if (act) {
+    split4_inputs<M, ROLE>(in_b + line, N, in);
+  } else {
+    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { in[decltype(i)::value] = 0.f; });
+  }
+  split4_transform<M, ROLE>(in, out);
+  if constexpr (FINAL) {
+    float e = 0.f;
+    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int k = decltype(i)::value;
+      e = fmaf(out[k], out[k], e);
+    });
+    if (!act) e = 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e += __shfl_down(e, off, 64);
+    if (lane == 0) *part = e;
+  } else {
+    if (act) {
+      dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int k = decltype(i)::value;
+        my[k * SWP + lane] = out[k];
+      });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nl = (N - strip * SW) < SW ? (N - strip * SW) : SW;
+#pragma unroll
+    for (int k0 = 0; k0 < M; k0 += 64) {  // M may exceed the 64 lanes of a wave
+      const int k = k0 + lane;
+      if (k < M) {
+        float* dst = t_b + (long long)(strip * SW) * N + ROLE * M + k;
+#pragma unroll 8
+        for (int j = 0; j < nl; ++j) dst[(long long)j * N] = my[k * SWP + j];
+      }
+    }
+  }
+}
+
+// grid.x = nmaps_in_launch * STRIPS; block = 4 waves (wave = role)
+// register budget: 4 waves/SIMD for M <= 40, 3 for M <= 56, 2 beyond
+template <int M>
+constexpr int split_waves_per_simd() { return M <= 40 ? 4 : (M <= 56 ? 3 : 2); }
+
+template <int M, bool FINAL>
+__global__ __launch_bounds__(256, (split_waves_per_simd<M>())) void k_pass1d(const float* __restrict__ in, long long in_map_stride,
+                                                float* __restrict__ t, float* __restrict__ partial) {
+  using Cfg = SplitCfg<M>;
+  __shared__ float slab[FINAL ? 1 : 4][FINAL ? 1 : Cfg::WAVE_LDS];
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const long long b = blockIdx.x / Cfg::STRIPS;
+  const int strip = blockIdx.x - (int)(b * Cfg::STRIPS);
+  const float* in_b = in + b * in_map_stride;
+  float* t_b = FINAL ? nullptr : t + b * (long long)Cfg::N * Cfg::N;
+  float* my = FINAL ? nullptr : slab[role];
+  float* part = partial + (long long)blockIdx.x * 4 + role;
+  switch (role) {
+    case 0: split4_wave<M, 0, FINAL>(in_b, t_b, my, strip, lane, part); break;
+    case 1: split4_wave<M, 1, FINAL>(in_b, t_b, my, strip, lane, part); break;
+    case 2: split4_wave<M, 2, FINAL>(in_b, t_b, my, strip, lane, part); break;
+    default: split4_wave<M, 3, FINAL>(in_b, t_b, my, strip, lane, part); break;
+  }
+}
+
+// out[b] = scale * sum of the map's 4*STRIPS partials, fixed order
+__global__ void k_split_reduce(const float* __restrict__ partial, int per_map, long long nmaps,
+                               float scale, float* __restrict__ out) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nmaps) return;
+  float s = 0.f;
+  for (int i = 0; i < per_map; ++i) s += partial[b * per_map + i];
+  out[b] = s * scale;
+}
+
+// ---------------------------------------------------------------------------------------
 // direct family: basis tables + separable transform
 // ---------------------------------------------------------------------------------------
 // Bt[r*n + k] = s_k cos(pi (2r+1) k / (2n)), s_0 = sqrt(1/n), s_k = sqrt(2/n)
@@ -390,6 +543,73 @@ int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipS
 #undef DCTS_CASE
 }
 
+// tile edges N = 4*M served by the split-4 family
+#define DCTS_SPLIT_M(X) X(18) X(20) X(28) X(32) X(36) X(40) X(56) X(64) X(72) X(80)
+
+bool has_split(long long HP, long long WP) {
+  if (HP != WP) return false;
+#define DCTS_CASE(M_) \
+  if (HP == 4 * M_) return true;
+  DCTS_SPLIT_M(DCTS_CASE)
+#undef DCTS_CASE
+  return false;
+}
+
+constexpr size_t kSplitChunkBytes = 96u << 20;  // intermediate tile buffer per launch pair
+
+struct SplitWs {
+  long long chunk_maps;
+  size_t off_t, off_part, total;
+};
+SplitWs split_ws(long long nmaps, int N) {
+  SplitWs w;
+  const size_t map_bytes = (size_t)N * N * 4;
+  long long chunk = (long long)(kSplitChunkBytes / map_bytes);
+  if (chunk < 1) chunk = 1;
+  if (chunk > nmaps) chunk = nmaps;
+  w.chunk_maps = chunk;
+  const int strips = (N + 63) / 64;
+  w.off_t = 0;
+  w.off_part = align_up((size_t)chunk * map_bytes, 256);
+  w.total = align_up(w.off_part + (size_t)chunk * strips * 4 * 4, 256);
+  return w;
+}
+
+template <int M>
+int launch_split(const MapGeom& g, float* out, void* workspace, hipStream_t st) {
+  using Cfg = SplitCfg<M>;
+  constexpr int N = Cfg::N;
+  const SplitWs ws = split_ws(g.nmaps, N);
+  char* wsp = reinterpret_cast<char*>(workspace);
+  float* T = reinterpret_cast<float*>(wsp + ws.off_t);
+  float* part = reinterpret_cast<float*>(wsp + ws.off_part);
+  const float* x0 = g.x + (long long)g.c_begin * g.strideC;
+  const float scale = float(4.0 / (double(N) * double(N)));
+  for (long long m0 = 0; m0 < g.nmaps; m0 += ws.chunk_maps) {
+    const long long nb = (g.nmaps - m0) < ws.chunk_maps ? (g.nmaps - m0) : ws.chunk_maps;
+    const unsigned grid = (unsigned)(nb * Cfg::STRIPS);
+    hipLaunchKernelGGL((k_pass1d<M, false>), dim3(grid), dim3(256), 0, st, x0 + m0 * g.strideC, g.strideC, T,
+                       part);
+    hipLaunchKernelGGL((k_pass1d<M, true>), dim3(grid), dim3(256), 0, st, T, (long long)N * N, (float*)nullptr,
+                       part);
+    hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, part,
+                       Cfg::STRIPS * 4, nb, scale, out + m0);
+  }
+  return (int)hipGetLastError();
+}
+
+int dispatch_split(int N, const MapGeom& g, float* out, void* workspace, hipStream_t st) {
+#define DCTS_CASE(M_) \
+  case 4 * M_:        \
+    return launch_split<M_>(g, out, workspace, st);
+  switch (N) {
+    DCTS_SPLIT_M(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+
 bool has_codelet(long long HP, long long WP) {
   if (HP != WP) return false;
 #define DCTS_CASE(N) \
@@ -429,10 +649,23 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
 
   const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
   if (algo == DCTS_ALGO_CODELET && !codelet_ok) return DCTS_E_UNSUPPORTED;
-  if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET)
+  if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET &&
+      algo != DCTS_ALGO_SPLIT)
     return DCTS_E_UNSUPPORTED;
   if (codelet_ok && algo != DCTS_ALGO_DIRECT)
     return dispatch_codelet<STORE>((int)HP, (int)WP, pad, g, out, st);
+  if constexpr (!STORE) {
+    const bool split_ok = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous &&
+                          strideC == H * W;
+    if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
+    if (split_ok && algo != DCTS_ALGO_DIRECT) {
+      const SplitWs sws = split_ws(g.nmaps, (int)HP);
+      if (!workspace || workspace_bytes < sws.total) return DCTS_E_WORKSPACE;
+      return dispatch_split((int)HP, g, out, workspace, st);
+    }
+  } else {
+    if (algo == DCTS_ALGO_SPLIT) return DCTS_E_UNSUPPORTED;
+  }
 
   const DirectWs ws = direct_ws(g.nmaps, (int)HP, (int)WP);
   if (!workspace) return ws.total ? DCTS_E_WORKSPACE : DCTS_E_NULL;
@@ -474,7 +707,12 @@ size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W) {
   if (N <= 0 || C_count <= 0 || H <= 0 || W <= 0) return 0;
   // worst case: odd front pad taken, direct kernel used
   const int64_t HP = H + 1, WP = W + 1;
-  return direct_ws(N * C_count, (int)HP, (int)WP).total;
+  size_t need = direct_ws(N * C_count, (int)HP, (int)WP).total;
+  if (has_split(H, W)) {
+    const size_t s = split_ws(N * C_count, (int)H).total;
+    if (s > need) need = s;
+  }
+  return need;
 }
 
 int dcts_has_codelet(int64_t H, int64_t W) { return has_codelet(H, W) ? 1 : 0; }

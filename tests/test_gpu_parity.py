@@ -58,6 +58,29 @@ def test_direct_sizes(n):
     check(x, got)
 
 
+SPLIT = [72, 80, 112, 128, 144, 160, 224, 256, 288, 320]
+
+
+@pytest.mark.parametrize("n", SPLIT)
+def test_split_sizes(n):
+    """Large tiles: two-launch split-4 codelet passes (N = 4*M)."""
+    x = synth(2, 11, n, n, 30 + n)
+    got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_SPLIT)
+    check(x, got)
+    assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks the same kernels
+    ref = orc.energy_nc(x[:1, :2])
+    assert rel_err(got[:1, :2].cpu(), ref) <= RTOL
+
+
+def test_split_chunking_many_maps():
+    """More maps than one intermediate-buffer chunk (96 MiB): 160x160 x 1200 maps."""
+    x = synth(4, 300, 160, 160, 77).cuda()
+    got = dpa.energy_nc(x, algo=dpa.ALGO_SPLIT).double()
+    ref = (x.double() ** 2).sum(dim=(-2, -1))
+    assert rel_err(got.cpu(), ref.cpu()) <= RTOL
+    assert (got[ref == 0] == 0).all()
+
+
 @pytest.mark.parametrize("hw", [(9, 18), (7, 14), (32, 16), (5, 3), (1, 1), (1, 7), (288, 3)])
 def test_non_square_direct(hw):
     h, w = hw
