@@ -23,6 +23,7 @@
 //                     fallback, compute-bound for large tiles.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dctscore.h"
 #include "codelet_sizes.h"
@@ -187,14 +188,13 @@ __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_cod
 // per-wave LDS transpose (coalesced stores), so the second launch of the same kernel
 // transforms the other axis. Final pass: squares are reduced per wave into partial sums.
 template <int M, int ROLE>
-__device__ __forceinline__ void split4_inputs(const float* __restrict__ col, long long rs,
-                                              float (&in)[M]) {
+__device__ __forceinline__ void split4_inputs(const float* col, int rs, float (&in)[M]) {
   dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
     constexpr int p = decltype(i)::value;
-    const float x0 = col[(long long)p * rs];
-    const float x1 = col[(long long)(2 * M - 1 - p) * rs];
-    const float x2 = col[(long long)(2 * M + p) * rs];
-    const float x3 = col[(long long)(4 * M - 1 - p) * rs];
+    const float x0 = col[p * rs];
+    const float x1 = col[(2 * M - 1 - p) * rs];
+    const float x2 = col[(2 * M + p) * rs];
+    const float x3 = col[(4 * M - 1 - p) * rs];
     if constexpr (ROLE == 0) {
       in[p] = (x0 + x3) + (x1 + x2);
     } else if constexpr (ROLE == 1) {
@@ -210,6 +210,9 @@ __device__ __forceinline__ void split4_inputs(const float* __restrict__ col, lon
         in[p] = d2 * (sg * c) - d1 * (sg * sn);
       }
     }
+    // keep the scheduler from hoisting every LDS read to the top (register pressure -> spills);
+    // ALU work may still move across (mask: 1 ALU | 2 VALU | 4 SALU)
+    if constexpr (p % 8 == 7) __builtin_amdgcn_sched_barrier(7);
   });
 }
 
@@ -230,24 +233,26 @@ template <int M>
 struct SplitCfg {
   static constexpr int N = 4 * M;
   static constexpr int STRIPS = (N + 63) / 64;
-  static constexpr int SW = (N + STRIPS - 1) / STRIPS;  // lines per strip (<= 64)
-  static constexpr int SWP = SW | 1;                    // odd LDS stride
-  static constexpr int WAVE_LDS = M * SWP;              // floats
+  static constexpr int SW = (((N + STRIPS - 1) / STRIPS) + 3) / 4 * 4;  // lines per strip, multiple of 4
+  static constexpr int SWP = SW | 1;                                    // odd LDS stride for the transpose
+  static constexpr int IN_LDS = N * SW;                                 // floats: the staged input strip
+  static constexpr int TR_LDS = 4 * M * SWP;                            // floats: 4 per-wave transpose slabs
+  static constexpr int LDS_NONFINAL = IN_LDS > TR_LDS ? IN_LDS : TR_LDS;
 };
 
+// register budget (waves/SIMD) chosen so that no role spills
+template <int M>
+constexpr int split_waves_per_simd() { return M <= 32 ? 4 : (M <= 40 ? 3 : (M <= 56 ? 2 : 1)); }
+
 template <int M, int ROLE, bool FINAL>
-__device__ __forceinline__ void split4_wave(const float* __restrict__ in_b, float* __restrict__ t_b,
-                                            float* my, int strip, int lane, float* part) {
+__device__ __forceinline__ void split4_wave(const float* lds_in, float* __restrict__ t_b, float* lds_tr,
+                                            int strip, int lane, float* part) {
   using Cfg = SplitCfg<M>;
   constexpr int N = Cfg::N, SW = Cfg::SW, SWP = Cfg::SWP;
   const int line = strip * SW + lane;
   const bool act = lane < SW && line < N;
   float in[M], out[M];
-  if (act) {
-    split4_inputs<M, ROLE>(in_b + line, N, in);
-  } else {
-    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { in[decltype(i)::value] = 0.f; });
-  }
+  split4_inputs<M, ROLE>(lds_in + (act ? lane : 0), SW, in);
   split4_transform<M, ROLE>(in, out);
   if constexpr (FINAL) {
     float e = 0.f;
@@ -260,6 +265,8 @@ __device__ __forceinline__ void split4_wave(const float* __restrict__ in_b, floa
     for (int off = 32; off >= 1; off >>= 1) e += __shfl_down(e, off, 64);
     if (lane == 0) *part = e;
   } else {
+    __syncthreads();  // every wave has consumed the staged strip: its LDS becomes the transpose slabs
+    float* my = lds_tr + ROLE * (M * SWP);
     if (act) {
       dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
         constexpr int k = decltype(i)::value;
@@ -282,28 +289,45 @@ __device__ __forceinline__ void split4_wave(const float* __restrict__ in_b, floa
   }
 }
 
-// grid.x = nmaps_in_launch * STRIPS; block = 4 waves (wave = role)
-// register budget: 4 waves/SIMD for M <= 40, 3 for M <= 56, 2 beyond
-template <int M>
-constexpr int split_waves_per_simd() { return M <= 40 ? 4 : (M <= 56 ? 3 : 2); }
-
+// grid.x = nmaps_in_launch * STRIPS; block = 4 waves (wave = role).
+// The strip In[b][0..N)[strip*SW .. +SW) is staged into LDS by direct-to-LDS loads
+// (global_load_lds_dwordx4: no VGPRs, the whole 4*M*SW*4-byte strip in flight at once), then
+// each role wave gathers its four mirrored rows per sample from LDS.
 template <int M, bool FINAL>
-__global__ __launch_bounds__(256, (split_waves_per_simd<M>())) void k_pass1d(const float* __restrict__ in, long long in_map_stride,
-                                                float* __restrict__ t, float* __restrict__ partial) {
+__global__ __launch_bounds__(256, (split_waves_per_simd<M>())) void k_pass1d(
+    const float* __restrict__ in, long long in_map_stride, float* __restrict__ t, float* __restrict__ partial) {
   using Cfg = SplitCfg<M>;
-  __shared__ float slab[FINAL ? 1 : 4][FINAL ? 1 : Cfg::WAVE_LDS];
+  constexpr int N = Cfg::N, SW = Cfg::SW;
+  __shared__ __attribute__((aligned(16))) float lds[FINAL ? Cfg::IN_LDS : Cfg::LDS_NONFINAL];
   const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
   const long long b = blockIdx.x / Cfg::STRIPS;
   const int strip = blockIdx.x - (int)(b * Cfg::STRIPS);
   const float* in_b = in + b * in_map_stride;
-  float* t_b = FINAL ? nullptr : t + b * (long long)Cfg::N * Cfg::N;
-  float* my = FINAL ? nullptr : slab[role];
+
+  constexpr int NQUADS = N * SW / 4;
+  constexpr int ITERS = (NQUADS + 255) / 256;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int qbase = it * 256 + role * 64;  // wave-uniform
+    const int q = qbase + lane;
+    const int e = 4 * q;
+    const int row = e / SW, col = e - row * SW;
+    if (q < NQUADS && strip * SW + col < N) {
+      const float* g = in_b + (long long)row * N + strip * SW + col;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(lds + 4 * qbase), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float* t_b = FINAL ? nullptr : t + b * (long long)N * N;
   float* part = partial + (long long)blockIdx.x * 4 + role;
   switch (role) {
-    case 0: split4_wave<M, 0, FINAL>(in_b, t_b, my, strip, lane, part); break;
-    case 1: split4_wave<M, 1, FINAL>(in_b, t_b, my, strip, lane, part); break;
-    case 2: split4_wave<M, 2, FINAL>(in_b, t_b, my, strip, lane, part); break;
-    default: split4_wave<M, 3, FINAL>(in_b, t_b, my, strip, lane, part); break;
+    case 0: split4_wave<M, 0, FINAL>(lds, t_b, lds, strip, lane, part); break;
+    case 1: split4_wave<M, 1, FINAL>(lds, t_b, lds, strip, lane, part); break;
+    case 2: split4_wave<M, 2, FINAL>(lds, t_b, lds, strip, lane, part); break;
+    default: split4_wave<M, 3, FINAL>(lds, t_b, lds, strip, lane, part); break;
   }
 }
 
@@ -555,7 +579,16 @@ bool has_split(long long HP, long long WP) {
   return false;
 }
 
-constexpr size_t kSplitChunkBytes = 96u << 20;  // intermediate tile buffer per launch pair
+// intermediate tile buffer per launch pair; DCTS_SPLIT_CHUNK_MB overrides (tuning knob)
+size_t split_chunk_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("DCTS_SPLIT_CHUNK_MB");
+    long mb = e ? atol(e) : 0;
+    if (mb < 1 || mb > 4096) mb = 256;
+    return (size_t)mb << 20;
+  }();
+  return v;
+}
 
 struct SplitWs {
   long long chunk_maps;
@@ -564,7 +597,7 @@ struct SplitWs {
 SplitWs split_ws(long long nmaps, int N) {
   SplitWs w;
   const size_t map_bytes = (size_t)N * N * 4;
-  long long chunk = (long long)(kSplitChunkBytes / map_bytes);
+  long long chunk = (long long)(split_chunk_bytes() / map_bytes);
   if (chunk < 1) chunk = 1;
   if (chunk > nmaps) chunk = nmaps;
   w.chunk_maps = chunk;
