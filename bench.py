@@ -280,8 +280,13 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(tpath):
+            # HBM bytes per launch from the committed PMC passes (tools/profile_pmc.sh: FETCH_SIZE and
+            # WRITE_SIZE in separate runs, read side corrected x2 by the dword-per-lane calibration
+            # kernel), scaled from the probe's launch size to this run's algorithmic bytes per launch
             try:
-                traffic = json.load(open(tpath)).get("k_energy_codelet_%d" % dom_edge, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath)).get("k_energy_codelet_%d_%d_0_false" % (dom_edge, dom_edge), {})
+                if rec.get("hbm_over_alg"):
+                    traffic = rec["hbm_over_alg"] * dom_bytes / n_launch
             except Exception:
                 traffic = None
         res = {

@@ -32,6 +32,7 @@ SIGNATURES = {
                                          _i32, _i32, _i32, _vp, _vp, _sz, _vp, _i32]),
     "dcts_batch_sum_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "dcts_running_mean_update_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.c_float, _vp]),
+    "dcts_debug_stream_read_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
 }
 
 

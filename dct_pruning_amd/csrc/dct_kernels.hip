@@ -512,6 +512,19 @@ __global__ __launch_bounds__(kSumCh * kSumSl) void k_running_mean(const float* _
   }
 }
 
+// PMC calibration aid: streams n floats with the codelet kernels' access width (one dword per
+// lane, consecutive lanes consecutive addresses) so FETCH_SIZE can be compared with a known
+// byte count in this exact pattern (MI355X_MICROARCH.md, HBM section: widths other than
+// 16 B/lane are uncalibrated).
+__global__ __launch_bounds__(256) void k_calib_read(const float* __restrict__ x, long long n,
+                                                    float* __restrict__ sink) {
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x)
+    s += x[i];
+  if (s == 123456.789f) sink[0] = s;  // keeps the loads alive without a store in practice
+}
+
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
@@ -801,6 +814,14 @@ int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_co
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(k_running_mean, dim3((unsigned)((C_count + kSumCh - 1) / kSumCh)), dim3(kSumCh * kSumSl), 0, st,
                      energy_nc, (long long)N, (long long)C_count, feature_result, total_before);
+  return (int)hipGetLastError();
+}
+
+int dcts_debug_stream_read_f32(const float* x, int64_t n, float* sink, void* stream) {
+  if (!x || !sink) return DCTS_E_NULL;
+  if (n <= 0) return DCTS_E_SHAPE;
+  hipLaunchKernelGGL(k_calib_read, dim3(256 * 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x,
+                     (long long)n, sink);
   return (int)hipGetLastError();
 }
 

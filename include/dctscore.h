@@ -145,6 +145,13 @@ int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float
 int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_count,
                                  float* feature_result, float total_before, void* stream);
 
+/*
+ * Measurement aid (not on the score path): reads n floats once with the kernels' own access
+ * width (one dword per lane, coalesced) and discards them. Used to calibrate the FETCH_SIZE
+ * performance counter against a known byte count (tools/pmc_traffic.py).
+ */
+int dcts_debug_stream_read_f32(const float* x, int64_t n, float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
