@@ -5,8 +5,8 @@ Workload (BASELINE.json configs[3], the one the metric's 1/2/4/8-GPU figures are
 the 49 hooked tensors of imp_score for resnet_50 (utils/common.py:557-607; shapes in
 dct_pruning_amd/schedules.py) at batch 256, fp32, synthetic, resident in HBM
 before the clock starts. One STEP = one batch pass of the hot path: for every hooked tensor
-one DCT+energy launch ([N,C,H,W] -> [N,C]) and one fused batch-sum/running-mean launch
-(utils/common.py:265-277). After the K timed steps (= `--limit K` batches) multi-GPU runs do
+one DCT+energy launch ([N,C,H,W] -> [N,C]), then one batch-sum/running-mean launch covering all
+hooked tensors (utils/common.py:265-277). After the K timed steps (= `--limit K` batches) multi-GPU runs do
 the path's single exchange: one RCCL all-gather of the flat score buffer; it is inside the
 timed region.
 
@@ -175,13 +175,19 @@ def main():
                      % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback in the product path)")
-    dev = torch.device("cuda", local_rank)
+    # rehearsal mode for a one-GPU box: DCTS_BENCH_REHEARSE=1 puts every rank on cuda:0 and runs the
+    # collective over gloo (through host memory); the driver's real runs use one GPU per rank + RCCL
+    rehearse = os.environ.get("DCTS_BENCH_REHEARSE") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dct_pruning_amd import _lib, schedules, sharding
     from dct_pruning_amd.ops import _workspace
@@ -217,23 +223,40 @@ def main():
     dom_edge = max(by_edge, key=by_edge.get)
     dom = [b for _, b in bound if b.h == dom_edge]
 
+    # launch order inside a step: all energy kernels grouped by tile edge (largest first), then ONE
+    # fused running-mean launch for every hook point (dcts_running_mean_update_multi_f32)
+    bound.sort(key=lambda ib: (-ib[1].h, ib[0]))
+    descs = (_lib.UpdateDesc * len(bound))()
+    for k, (_, b) in enumerate(bound):
+        descs[k].energy_nc, descs[k].feature_result = b.energy.data_ptr(), b.fr.data_ptr()
+        descs[k].N, descs[k].C_count = b.n, b.fr.numel()
+
     def step(events=None):
+        in_dom = False
         for _, b in bound:
-            if events is not None and b.h == dom_edge:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                b.launch_energy()
-                e1.record()
-                events.append((e0, e1, b.bytes))
-            else:
-                b.launch_energy()
-            b.launch_update()
+            if events is not None and (b.h == dom_edge) != in_dom:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                events.append(ev)
+                in_dom = not in_dom
+            b.launch_energy()
+        if events is not None and in_dom:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            events.append(ev)
+        for k, (_, b) in enumerate(bound):
+            descs[k].total_before = b.total
+            b.total += b.n
+        rc = lib.dcts_running_mean_update_multi_f32(descs, len(bound), stream_ptr)
+        if rc:
+            raise RuntimeError("dcts_running_mean_update_multi_f32 -> %d" % rc)
 
     def gather():
         flat = torch.zeros(seg, dtype=torch.float32, device=dev)
         for i, b in bound:
             flat[off[i]:off[i] + b.fr.numel()] = b.fr
+        if rehearse and world > 1:
+            return sharding.all_gather_scores(flat.cpu(), world).to(dev)
         return sharding.all_gather_scores(flat, world)
 
     def barrier():
@@ -259,7 +282,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
@@ -271,9 +294,10 @@ def main():
     if not rel <= 1e-4:
         sys.exit("bench sanity check failed: rel err %g" % rel)
 
-    dom_ms = sum(a.elapsed_time(b) for a, b, _ in events)
-    dom_bytes = sum(by for _, _, by in events)
-    n_launch = max(len(events), 1)
+    # events come in (start, stop) pairs around each contiguous group of dominant-kernel launches
+    dom_ms = sum(events[i].elapsed_time(events[i + 1]) for i in range(0, len(events), 2))
+    dom_bytes = sum(b.bytes for b in dom) * args.steps
+    n_launch = max(len(dom) * args.steps, 1)
 
     if rank == 0:
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -302,7 +326,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_energy_codelet<%d,%d>" % (dom_edge, dom_edge),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": len(events), "avg_launch_us": dom_ms / n_launch * 1e3,
+                         "launches": n_launch, "avg_launch_us": dom_ms / n_launch * 1e3,
                          "alg_bytes_per_launch": dom_bytes / n_launch},
             "parity_check_rel_err": rel,
         }

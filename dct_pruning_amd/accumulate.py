@@ -6,6 +6,10 @@ HostAccumulator   reference-exact: per-map energies come back to the host and th
 DeviceAccumulator the fused device form (dcts_running_mean_update_f32): nothing leaves the
                   GPU until the scores are read; same rounding sequence, batch sum in
                   ascending n instead of torch's pairwise sum(0).
+DeviceBatchAccumulator  many hook points at once (single-sweep harness): the per-layer updates of
+                  a batch are deferred and issued as ONE launch
+                  (dcts_running_mean_update_multi_f32) when the next batch starts or the
+                  scores are read.
 """
 import torch
 
@@ -57,3 +61,40 @@ class DeviceAccumulator:
 
     def scores(self):
         return self.feature_result.cpu().numpy()
+
+
+class DeviceBatchAccumulator:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.state = {}    # key -> [feature_result tensor, total]
+        self.pending = {}  # key -> energy tensor of the current batch
+
+    def add(self, key, energy_nc):
+        if key in self.pending:  # the same hook fired again: a new batch has started
+            self.flush()
+        e = energy_nc.contiguous()
+        if key not in self.state:
+            self.state[key] = [torch.zeros(e.shape[1], dtype=torch.float32, device=self.device), 0.0]
+        self.pending[key] = e
+
+    def flush(self):
+        if not self.pending:
+            return
+        keys = list(self.pending)
+        descs = (_lib.UpdateDesc * len(keys))()
+        for i, k in enumerate(keys):
+            e, (fr, total) = self.pending[k], self.state[k]
+            descs[i].energy_nc, descs[i].feature_result = e.data_ptr(), fr.data_ptr()
+            descs[i].N, descs[i].C_count, descs[i].total_before = e.shape[0], e.shape[1], float(total)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().dcts_running_mean_update_multi_f32(descs, len(keys), stream))
+        for k in keys:
+            self.state[k][1] += self.pending[k].shape[0]
+        # the launch is enqueued on the stream the energies were produced on: dropping the references
+        # now is safe for the caching allocator (same-stream reuse is ordered after the kernel)
+        self.pending.clear()
+
+    def scores(self, key):
+        self.flush()
+        return self.state[key][0].cpu().numpy()

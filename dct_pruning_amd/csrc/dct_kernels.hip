@@ -512,6 +512,25 @@ __global__ __launch_bounds__(kSumCh * kSumSl) void k_running_mean(const float* _
   }
 }
 
+// the same update for up to kMultiMax hook points in one launch (descriptors by value in the
+// kernel arguments): blockIdx.y = hook point, blockIdx.x = 32-channel strip
+constexpr int kMultiMax = 64;
+struct UpdateBatch {
+  dcts_update_desc d[kMultiMax];
+};
+__global__ __launch_bounds__(kSumCh * kSumSl) void k_running_mean_multi(UpdateBatch b) {
+  __shared__ float part[kSumSl][kSumCh];
+  const dcts_update_desc d = b.d[blockIdx.y];
+  if ((long long)blockIdx.x * kSumCh >= d.C_count) return;  // whole block leaves together
+  const int slice = threadIdx.x / kSumCh;
+  const long long j = (long long)blockIdx.x * kSumCh + threadIdx.x % kSumCh;
+  const float t = strip_batch_sum(d.energy_nc, d.N, d.C_count, j, slice, part);
+  if (slice == 0 && j < d.C_count) {
+    const float acc = __fadd_rn(__fmul_rn(d.feature_result[j], d.total_before), t);
+    d.feature_result[j] = __fdiv_rn(acc, __fadd_rn(d.total_before, float(d.N)));
+  }
+}
+
 // PMC calibration aid: streams n floats with the codelet kernels' access width (one dword per
 // lane, consecutive lanes consecutive addresses) so FETCH_SIZE can be compared with a known
 // byte count in this exact pattern (MI355X_MICROARCH.md, HBM section: widths other than
@@ -814,6 +833,27 @@ int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_co
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(k_running_mean, dim3((unsigned)((C_count + kSumCh - 1) / kSumCh)), dim3(kSumCh * kSumSl), 0, st,
                      energy_nc, (long long)N, (long long)C_count, feature_result, total_before);
+  return (int)hipGetLastError();
+}
+
+int dcts_running_mean_update_multi_f32(const dcts_update_desc* descs, int32_t count, void* stream) {
+  if (!descs) return DCTS_E_NULL;
+  if (count <= 0) return DCTS_E_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int32_t i0 = 0; i0 < count; i0 += kMultiMax) {
+    const int n = (count - i0) < kMultiMax ? (count - i0) : kMultiMax;
+    UpdateBatch b;
+    int64_t cmax = 0;
+    for (int i = 0; i < n; ++i) {
+      b.d[i] = descs[i0 + i];
+      if (!b.d[i].energy_nc || !b.d[i].feature_result) return DCTS_E_NULL;
+      if (b.d[i].N <= 0 || b.d[i].C_count <= 0) return DCTS_E_SHAPE;
+      if (b.d[i].C_count > cmax) cmax = b.d[i].C_count;
+    }
+    for (int i = n; i < kMultiMax; ++i) b.d[i] = b.d[0];
+    hipLaunchKernelGGL(k_running_mean_multi, dim3((unsigned)((cmax + kSumCh - 1) / kSumCh), (unsigned)n),
+                       dim3(kSumCh * kSumSl), 0, st, b);
+  }
   return (int)hipGetLastError();
 }
 

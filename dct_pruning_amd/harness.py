@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import ops, schedules, sharding
-from .accumulate import DeviceAccumulator, HostAccumulator
+from .accumulate import DeviceAccumulator, DeviceBatchAccumulator, HostAccumulator
 
 # tests swap this for the oracle to exercise the host logic without a GPU
 _energy_nc = ops.energy_nc
@@ -137,18 +137,25 @@ def _save(out_dir, net_name, pt, scores):
 
 
 class _PointHook:
-    """A hook with its own accumulator (single-sweep / device modes)."""
+    """A hook with its own accumulator (single-sweep / device modes). With `batch` set, the
+    device-side update is deferred and fused across hook points (DeviceBatchAccumulator)."""
 
-    def __init__(self, kind, accumulate, device):
+    def __init__(self, kind, accumulate, device, batch=None, key=None):
         self.kind, self.accumulate, self.device, self.acc = kind, accumulate, device, None
+        self.batch, self.key = batch, key
 
     def __call__(self, module, inputs, output):
         e = _hook_energy(self.kind, _scored_tensor(self.kind, inputs, output))
+        if self.batch is not None:
+            self.batch.add(self.key, e)
+            return
         if self.acc is None:
             self.acc = DeviceAccumulator(e.shape[1], e.device) if self.accumulate == "device" else HostAccumulator()
         self.acc.update(e)
 
     def scores(self):
+        if self.batch is not None:
+            return np.ascontiguousarray(self.batch.scores(self.key), dtype=np.float32)
         return np.ascontiguousarray(self.acc.scores(), dtype=np.float32)
 
 
@@ -191,8 +198,9 @@ def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host
 
     if single_sweep:
         hooks, handles = {}, []
+        batch = DeviceBatchAccumulator(dev) if (accumulate == "device" and dev.type == "cuda") else None
         for i in mine:
-            hooks[i] = _PointHook(pts[i].kind, accumulate, dev)
+            hooks[i] = _PointHook(pts[i].kind, accumulate, dev, batch=batch, key=i)
             handles.append(_resolve(net, pts[i].module).register_forward_hook(hooks[i]))
         sweep(net, train_loader, args.limit)
         for h in handles:

@@ -146,6 +146,21 @@ int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_co
                                  float* feature_result, float total_before, void* stream);
 
 /*
+ * The same update for `count` hook points in ONE launch (single-sweep harness: every layer's
+ * energies of a batch are ready when the forward pass ends). `descs` is a HOST array; it is
+ * copied into the kernel arguments, so it may be reused as soon as the call returns.
+ */
+typedef struct dcts_update_desc {
+  const float* energy_nc; /* [N, C_count] device */
+  float* feature_result;  /* [C_count] device, in/out */
+  int64_t N;
+  int64_t C_count;
+  float total_before;     /* samples accumulated so far for this hook point */
+  int32_t reserved;
+} dcts_update_desc;
+int dcts_running_mean_update_multi_f32(const dcts_update_desc* descs, int32_t count, void* stream);
+
+/*
  * Measurement aid (not on the score path): reads n floats once with the kernels' own access
  * width (one dword per lane, coalesced) and discards them. Used to calibrate the FETCH_SIZE
  * performance counter against a known byte count (tools/pmc_traffic.py).
