@@ -10,6 +10,7 @@ from .ops import (  # noqa: F401
     ALGO_AUTO,
     ALGO_CODELET,
     ALGO_DIRECT,
+    ALGO_PREFETCH,
     ALGO_SPLIT,
     batch_sum,
     dct2d,
@@ -17,4 +18,4 @@ from .ops import (  # noqa: F401
     has_codelet,
 )
 
-__all__ = ["energy_nc", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT"]
+__all__ = ["energy_nc", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH"]

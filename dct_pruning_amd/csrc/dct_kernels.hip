@@ -57,8 +57,13 @@ template <int HP, int WP>
 struct CodeletCfg {
   static constexpr int EDGE = HP > WP ? HP : WP;
   static constexpr int G = 64 / EDGE;           // maps per wave per iteration
-  static constexpr int S = WP | 1;              // odd LDS row stride (floats)
-  static constexpr int MAP_LDS = HP * S;        // floats per map in the transpose slab
+  // LDS row stride S and per-map stride: odd S is conflict-free inside one map; when several maps
+  // share a wave the pair (S, MAP_LDS) below keeps the G*edge lanes of a half-wave on distinct
+  // banks for both the column-wise store and the row-wise load (brute-force search over paddings,
+  // SQ_LDS_BANK_CONFLICT was 18-47 % of LDS cycles before for these edges)
+  static constexpr int S = (HP == WP && WP == 7) ? 8 : (HP == WP && (WP == 10 || WP == 14)) ? 17
+                         : (HP == WP && WP == 20) ? 25 : (HP == WP && WP == 28) ? 33 : (WP | 1);
+  static constexpr int MAP_LDS = (HP == WP && WP == 7) ? 71 : HP * S;  // floats per map in the transpose slab
   static constexpr int WAVE_LDS = G * MAP_LDS;  // floats per wave
   // waves per workgroup: keep a workgroup's slab <= 48 KiB so >= 3 workgroups fit a CU
   static constexpr int WAVES = (WAVE_LDS * 4 * 4 <= 49152) ? 4 : ((WAVE_LDS * 4 * 2 <= 49152) ? 2 : 1);
@@ -162,6 +167,115 @@ __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_cod
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+// Prefetching variant for dense square even-edge tiles (the common case: every hooked tensor of
+// the reference nets except 7x7 / 9x9). Same two passes and the same LDS slab, but the NEXT
+// group of maps is streamed into the slab with direct-to-LDS loads (global_load_lds_dwordx4, no
+// VGPRs) as soon as pass 2 has read the transposed tile out of it, so the HBM latency of group
+// i+1 hides under the pass-2 codelet of group i instead of stalling the wave (s_waitcnt was
+// 28 % of the wave's cycles in k_energy_codelet). Pass 1 then reads its column from the linear
+// LDS image (lane = column: consecutive addresses, conflict-free).
+template <int N>
+__global__ __launch_bounds__((64 * CodeletCfg<N, N>::WAVES)) void k_energy_codelet_dma(
+    MapGeom g, float* __restrict__ out) {
+  using Cfg = CodeletCfg<N, N>;
+  constexpr int G = Cfg::G, S = Cfg::S, MAP_LDS = Cfg::MAP_LDS, WAVES = Cfg::WAVES;
+  constexpr int NN = N * N;
+  constexpr int QPG = G * NN / 4;                // 16-byte quads per full group
+  constexpr int DMA_IT = (QPG + 63) / 64;        // direct-to-LDS instructions per group
+  constexpr int SLAB = ((Cfg::WAVE_LDS > DMA_IT * 256 ? Cfg::WAVE_LDS : DMA_IT * 256) + 3) / 4 * 4;
+  static_assert((G * NN) % 4 == 0, "group must be a whole number of 16-byte quads");
+  __shared__ __attribute__((aligned(16))) float slab[WAVES][SLAB];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* my = slab[wave];
+  const int g1 = lane / N, c = lane - g1 * N;  // square tile: pass-1 and pass-2 roles coincide
+  const bool act = g1 < G;
+
+  const long long ngroups = (g.nmaps + G - 1) / G;
+  const long long wave_gid = (long long)blockIdx.x * WAVES + wave;
+  const long long nwaves = (long long)gridDim.x * WAVES;
+  const float* x0 = g.x + (long long)g.c_begin * g.strideC;  // dense: map m starts at x0 + m*NN
+
+  auto prefetch = [&](long long grp) DCTS_LAMBDA_INLINE {
+    const long long m0 = grp * G;
+    const long long left = g.nmaps - m0;
+    const int nq = (int)((left < G ? left : G) * (NN / 4));
+    const float* src = x0 + m0 * NN;
+#pragma unroll
+    for (int it = 0; it < DMA_IT; ++it) {
+      const int q = it * 64 + lane;
+      if (q < nq)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * q),
+                                         (__attribute__((address_space(3))) void*)(my + it * 256), 16, 0, 0);
+    }
+  };
+
+  if (wave_gid < ngroups) prefetch(wave_gid);
+  for (long long grp = wave_gid; grp < ngroups; grp += nwaves) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group's tiles have landed in LDS
+    const long long m1 = grp * G + g1;
+    const bool valid = act && m1 < g.nmaps;
+    // ---- pass 1: column DCT-II, lane = column, input from the linear LDS image --------
+    float xr[N], y[N];
+    {
+      const float* src = my + (valid ? g1 * NN + c : 0);
+      dcts::static_for<N>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int r = decltype(i)::value;
+        xr[r] = src[r * N];
+      });
+      if (!valid) dcts::static_for<N>([&](auto i) DCTS_LAMBDA_INLINE { xr[decltype(i)::value] = 0.f; });
+    }
+    dcts::Dct2<N>::run(xr, y);
+    y[0] *= dcts::kInvSqrt2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+      float* dst = my + g1 * MAP_LDS + c;
+      dcts::static_for<N>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int kk = decltype(i)::value;
+        dst[kk * S] = y[kk];
+      });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- pass 2: row DCT-II, lane = row -----------------------------------------------
+    float z[N], w[N];
+    {
+      const float* src = my + (act ? g1 : 0) * MAP_LDS + (act ? c : 0) * S;
+      dcts::static_for<N>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int cc = decltype(i)::value;
+        z[cc] = src[cc];
+      });
+    }
+    // the slab is free once these reads have returned: stream the next group into it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (grp + nwaves < ngroups) prefetch(grp + nwaves);
+    dcts::Dct2<N>::run(z, w);
+    w[0] *= dcts::kInvSqrt2;
+    float e = 0.f;
+    dcts::static_for<N>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int l = decltype(i)::value;
+      e = fmaf(w[l], w[l], e);
+    });
+    if (!act) e = 0.f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      if (off < N) {
+        const float t = __shfl_down(e, off, 64);
+        if (c + off < N) e += t;
+      }
+    }
+    if (valid && c == 0) {
+      constexpr float sc = float(4.0 / (double(N) * double(N)));
+      out[m1] = e * sc;
+    }
   }
 }
 
@@ -579,6 +693,50 @@ int launch_codelet(const MapGeom& g, float* out, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+template <int N>
+int launch_codelet_dma(const MapGeom& g, float* out, hipStream_t st) {
+  using Cfg = CodeletCfg<N, N>;
+  if constexpr ((Cfg::G * N * N) % 4 != 0) {
+    return DCTS_E_UNSUPPORTED;
+  } else {
+    const long long ngroups = (g.nmaps + Cfg::G - 1) / Cfg::G;
+    long long blocks = (ngroups + Cfg::WAVES - 1) / Cfg::WAVES;
+    // persistent grid = exactly one residency: every wave then loops over many groups and the
+    // prefetch of group i+1 overlaps the arithmetic of group i
+    static const int per_cu = [] {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_energy_codelet_dma<N>, 64 * Cfg::WAVES, 0) != hipSuccess ||
+          n < 1)
+        n = 1;
+      return n;
+    }();
+    const long long cap = (long long)kNumCU * per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((k_energy_codelet_dma<N>), dim3((unsigned)blocks), dim3(64 * Cfg::WAVES), 0, st, g, out);
+    return (int)hipGetLastError();
+  }
+}
+
+// dense, 16-byte aligned, even-edge square tiles take the prefetching kernel
+bool dma_ok(int HP, int WP, int pad, const MapGeom& g) {
+  if (pad || HP != WP || (HP % 2) != 0) return false;
+  if (!g.contiguous || g.strideC != (long long)HP * WP) return false;
+  return (reinterpret_cast<uintptr_t>(g.x + (long long)g.c_begin * g.strideC) & 15) == 0;
+}
+
+int dispatch_codelet_dma(int N, const MapGeom& g, float* out, hipStream_t st) {
+#define DCTS_CASE(N_) \
+  case N_:            \
+    return launch_codelet_dma<N_>(g, out, st);
+  switch (N) {
+    DCTS_CODELET_SIZES(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+
 template <bool STORE>
 int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipStream_t st) {
   if (HP != WP) return DCTS_E_UNSUPPORTED;
@@ -713,12 +871,23 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
   const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
-  if (algo == DCTS_ALGO_CODELET && !codelet_ok) return DCTS_E_UNSUPPORTED;
+  if ((algo == DCTS_ALGO_CODELET || algo == DCTS_ALGO_PREFETCH) && !codelet_ok) return DCTS_E_UNSUPPORTED;
   if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET &&
-      algo != DCTS_ALGO_SPLIT)
+      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH)
     return DCTS_E_UNSUPPORTED;
-  if (codelet_ok && algo != DCTS_ALGO_DIRECT)
+  if (codelet_ok && algo != DCTS_ALGO_DIRECT) {
+    if constexpr (!STORE) {
+      // the prefetching variant is opt-in: on MI355X it measured equal to the register-load
+      // kernel in steady state (both at the practical HBM rate) and ~2 % slower on the bench
+      if (algo == DCTS_ALGO_PREFETCH) {
+        if (!dma_ok((int)HP, (int)WP, pad, g)) return DCTS_E_UNSUPPORTED;
+        return dispatch_codelet_dma((int)HP, g, out, st);
+      }
+    } else if (algo == DCTS_ALGO_PREFETCH) {
+      return DCTS_E_UNSUPPORTED;
+    }
     return dispatch_codelet<STORE>((int)HP, (int)WP, pad, g, out, st);
+  }
   if constexpr (!STORE) {
     const bool split_ok = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous &&
                           strideC == H * W;

@@ -45,6 +45,15 @@ def test_codelet_sizes(n):
     x = synth(3, 19, n, n, 10 + n)
     got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_CODELET)
     check(x, got)
+    auto = dpa.energy_nc(x.cuda())
+    assert torch.equal(auto, got)  # AUTO = the register-load codelet kernel
+    if n % 2 == 0:
+        # opt-in prefetching (direct-to-LDS) variant; many groups per wave exercise its loop
+        check(x, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_PREFETCH))
+        big = synth(40, 77, n, n, 11 + n).cuda()
+        pre = dpa.energy_nc(big, algo=dpa.ALGO_PREFETCH)
+        check(big.cpu(), pre)
+        assert torch.equal(pre, dpa.energy_nc(big, algo=dpa.ALGO_PREFETCH))
     # per-map loop oracle on a subset (the reference's exact loop structure)
     ref = orc.energy_nc(x[:1, :4])
     assert rel_err(got[:1, :4].cpu(), ref) <= RTOL
@@ -207,3 +216,14 @@ def test_device_accumulator_matches_reference_rule():
     np.testing.assert_allclose(host.scores(), st.feature_result.numpy(), rtol=RTOL)
     dead = np.arange(37) % 8 == 5
     assert (dev.scores()[dead] == 0).all() and (host.scores()[dead] == 0).all()
+
+
+def test_direct_kernel_workgroups_reuse_their_scratch_tile():
+    """More maps than resident workgroups (grid cap 512): each workgroup loops and overwrites its
+    intermediate tile in the workspace, so stale cache lines would show up here."""
+    for n, c, h in [(3, 700, 24), (2, 600, 12), (1, 1100, 33)]:
+        x = synth(n, c, h, h, 500 + h)
+        got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT)
+        check(x, got)
+        again = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT)
+        assert torch.equal(got, again)
