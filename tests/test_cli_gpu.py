@@ -1,0 +1,77 @@
+"""End to end on the GPU: importance_generation.py (the reference's CLI surface) -> score files ->
+prune masks, for BASELINE.json config 2 (VGG-16-bn / CIFAR shapes, limit 5) at a reduced batch and
+a ResNet-50 / 224x224 run at batch 2. Masks are compared with the masks of scores computed by
+the CPU oracle on the very same activations."""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from dct_pruning_amd import harness, masks, nets, schedules
+from dct_pruning_amd.data import load_data
+from oracle import dct_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_cli(tmp_path, *argv):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "importance_generation.py"), *argv], cwd=tmp_path,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout
+    return p.stdout
+
+
+def oracle_scores(name, args, points):
+    """Same seeds as the CLI: same net, same synthetic batches; energies by the CPU oracle."""
+    torch.manual_seed(args.seed)
+    net = nets.get_network(name).cuda().eval()
+    loader, _ = load_data(args)
+    acts = {}
+    handles = [harness._resolve(net, p.module).register_forward_hook(
+        lambda m, i, o, _p=p: acts.setdefault(_p.module, []).append(
+            (i[0] if _p.kind == "input" else o).detach().cpu())) for p in points]
+    harness.inference(net, loader, args.limit)
+    for h in handles:
+        h.remove()
+    out = {}
+    for p in points:
+        st = orc.HookState()
+        for a in acts[p.module]:
+            cb, cc, pad = schedules.scored_shape(p._replace(C=a.shape[1]))
+            st.update(orc.energy_nc_batched(a, cb, cc, pad).sum(0), a.shape[0])
+        out[p.files[0][0]] = st.feature_result.numpy()
+    return out
+
+
+@pytest.mark.parametrize("name,bs,limit,extra", [("vgg_16_bn", 32, 5, []), ("resnet_50", 2, 2, []),
+                                                  ("vgg_16_bn", 32, 5, ["--single_sweep", "--device_accumulate"])])
+def test_cli_to_masks(tmp_path, name, bs, limit, extra):
+    out = run_cli(tmp_path, "--net", name, "--synthetic", "--pretrain_dir", "", "--batch_size", str(bs),
+                  "--limit", str(limit), *extra)
+    assert "The importance score generation has been completed!" in out
+    d = tmp_path / "importance_score" / ("%s_limit%d" % (name, limit))
+    pts = schedules.SCHEDULES[name]()
+    assert sorted(os.listdir(d)) == sorted(s + ".npy" for p in pts for s, _, _ in p.files)
+    args = types.SimpleNamespace(net=name, dataset="cifar10" if name != "resnet_50" else "imagenet", synthetic=True,
+                                 batch_size=bs, limit=limit, seed=0, input_size=None)
+    some = pts[:4] + pts[-3:]
+    ref = oracle_scores(name, args, some)
+    for stem, r in ref.items():
+        got = np.load(d / (stem + ".npy"))
+        assert got.dtype == np.float32 and got.shape == r.shape
+        # the forward pass re-runs here (MIOpen is not bit-reproducible run to run): 1e-4, not bitwise
+        np.testing.assert_allclose(got, r, rtol=1e-4, atol=1e-6 * float(r.max()))
+        for rate in (0.3, 0.5, 0.95):
+            k = int(r.size * (1 - rate))
+            a, b = masks.select_index(got, r.size, k), masks.select_index(r, r.size, k)
+            # identical unless a near-tie (|delta| < 1e-4 relative) straddles the cut
+            if not np.array_equal(a, b):
+                diff = np.setxor1d(a, b)
+                cut = np.sort(r)[r.size - k]
+                assert np.all(np.abs(r[diff] - cut) <= 2e-4 * abs(cut)), stem
