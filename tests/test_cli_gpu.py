@@ -52,13 +52,14 @@ def oracle_scores(name, args, points):
 @pytest.mark.parametrize("name,bs,limit,extra", [("vgg_16_bn", 32, 5, []), ("resnet_50", 2, 2, []),
                                                   ("vgg_16_bn", 32, 5, ["--single_sweep", "--device_accumulate"])])
 def test_cli_to_masks(tmp_path, name, bs, limit, extra):
-    out = run_cli(tmp_path, "--net", name, "--synthetic", "--pretrain_dir", "", "--batch_size", str(bs),
-                  "--limit", str(limit), *extra)
+    dataset = "imagenet" if name == "resnet_50" else "cifar10"
+    out = run_cli(tmp_path, "--net", name, "--dataset", dataset, "--synthetic", "--pretrain_dir", "",
+                  "--batch_size", str(bs), "--limit", str(limit), *extra)
     assert "The importance score generation has been completed!" in out
     d = tmp_path / "importance_score" / ("%s_limit%d" % (name, limit))
     pts = schedules.SCHEDULES[name]()
     assert sorted(os.listdir(d)) == sorted(s + ".npy" for p in pts for s, _, _ in p.files)
-    args = types.SimpleNamespace(net=name, dataset="cifar10" if name != "resnet_50" else "imagenet", synthetic=True,
+    args = types.SimpleNamespace(net=name, dataset=dataset, synthetic=True,
                                  batch_size=bs, limit=limit, seed=0, input_size=None)
     some = pts[:4] + pts[-3:]
     ref = oracle_scores(name, args, some)
