@@ -203,7 +203,10 @@ def main():
     chans = [s[1] for s in scored]
     cost_pc = [float(N * (4 * p.H * p.W + 4)) for p in points]
     total_cost = sum(c * k for c, k in zip(chans, cost_pc))
-    units = sharding.make_units(chans, cost_pc, max_unit_cost=(total_cost / (world * 6)) if world > 1 else None)
+    # whole hook points (layers) are the units; wide layers are only cut into channel ranges when
+    # there are too few layers per rank for LPT to balance (49 layers over 8 ranks: 2.3 % imbalance)
+    split = (total_cost / (world * 3)) if world * 4 > len(points) else None
+    units = sharding.make_units(chans, cost_pc, max_unit_cost=split)
     owner, load = sharding.assign(units, world)
     off, seg = sharding.layout(units, owner, world)
 
@@ -320,7 +323,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s hooked feature maps (49 tensors, %d maps/sample: 56x56 x1344, 28x28 x3200, "
                                    "14x14 x9472, 7x7 x8704), batch %d, limit=steps" % (args.net, sum(chans), N),
-                       "global_batch": N, "sharding": "layer/channel-range units, LPT, 1 all-gather" if world > 1 else "none",
+                       "global_batch": N, "sharding": "layer-sharded (LPT on bytes), 1 all-gather" if world > 1 else "none",
                        "units_rank0": len(bound), "load_imbalance": (max(load) / (sum(load) / world)) if world > 1 else 1.0},
             "GB_s_whole_step": total_cost * args.steps / dt / 1e9,
             "roofline": {"bound": "hbm", "kernel": "k_energy_codelet<%d,%d>" % (dom_edge, dom_edge),
