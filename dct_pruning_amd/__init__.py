@@ -10,6 +10,7 @@ from .ops import (  # noqa: F401
     ALGO_AUTO,
     ALGO_CODELET,
     ALGO_DIRECT,
+    ALGO_FUSED,
     ALGO_PREFETCH,
     ALGO_SPLIT,
     batch_sum,
@@ -18,4 +19,4 @@ from .ops import (  # noqa: F401
     has_codelet,
 )
 
-__all__ = ["energy_nc", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH"]
+__all__ = ["energy_nc", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED"]

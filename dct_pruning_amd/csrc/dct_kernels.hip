@@ -280,94 +280,252 @@ __global__ __launch_bounds__((64 * CodeletCfg<N, N>::WAVES)) void k_energy_codel
 }
 
 // ---------------------------------------------------------------------------------------
-// split-4 family: tiles whose edge N = 4*M is too long for one lane's registers
+// split family: tiles whose edge N = 2^L * M is too long for one lane's registers
 // ---------------------------------------------------------------------------------------
-// A length-N DCT-II is cut by two radix-2 levels into four length-M problems ("roles"),
-// each run by one lane with an M-point codelet (dct_codelets.hpp recursion, top two levels
-// unrolled across waves instead of inside a lane). With x3 = x[N-1-p], x1 = x[2M-1-p],
-// x2 = x[2M+p], beta_p = (2p+1) pi / (8M):
-//   role 0: in[p] = (x[p] + x3) + (x1 + x2)                  DCT-II_M  -> X[4k]
-//   role 1: in[p] = (x[p] + x3) - (x1 + x2)                  DCT-IV_M  -> X[4k+2]
-//   role 2: in[p] =  (x[p] - x3) cos(beta) + (x1 - x2) sin(beta)            DCT-II_M -> A[k]
-//   role 3: in[p] = (-1)^p ((x1 - x2) cos(beta) - (x[p] - x3) sin(beta))    DCT-II_M -> B[k]
-// and the odd outputs are X[2(2j)+1] = A[j] + B[M-j], X[2(2j-1)+1] = A[j] - B[M-j] (0<j<M),
-// X[1] = A[0], X[2N-1...] = -B[0]. That last add/sub layer is a 45-degree rotation of each
-// pair scaled by sqrt(2); the energy kernels fuse it into the reduction,
-// (a+b)^2 + (a-b)^2 = 2a^2 + 2b^2, i.e. A[k], B[k] (k>0) are carried with weight sqrt(2).
-// Every other butterfly, rotation and twiddle of the transform is computed.
+// The top L radix-2 levels of the codelet recursion (dct_codelets.hpp) are unrolled across
+// 2^L "role" waves instead of inside a lane; each role runs an M-point codelet on a length-M
+// input it gathers from 2^L mirrored samples. The role tree, with y the input of a node:
+//   DCT-II node (length n):  child 0 = DCT-II(n/2) of y[j] + y[n-1-j]
+//                            child 1 = DCT-IV(n/2) of y[j] - y[n-1-j]
+//   DCT-IV node (length n):  child 0 = DCT-II(n/2) of  y[j] cos(b_j) + y[n-1-j] sin(b_j)
+//                            child 1 = DCT-II(n/2) of (-1)^j (y[n-1-j] cos(b_j) - y[j] sin(b_j)),
+//                            b_j = (2j+1) pi / (4n); outputs A (child 0), B (child 1)
+// A DCT-II node's outputs are its children's, interleaved (exact). A DCT-IV node's outputs are
+// X[0] = A[0], X[n-1] = -B[0], X[2j] = A[j] + B[n/2-j], X[2j-1] = A[j] - B[n/2-j]: that last
+// add/sub layer is a rotation of each pair scaled by sqrt(2); the energy kernels fuse it into the
+// reduction, (a+b)^2 + (a-b)^2 = 2a^2 + 2b^2, i.e. A[j], B[j] (j > 0) are carried with weight
+// sqrt(2) (SplitNode::wt). Every other butterfly, rotation and twiddle is computed.
 //
-// k_pass1d transforms the row axis of In[b][n][line] (lines contiguous), one wave per
-// (64-line strip, role), the four role waves of a strip in one workgroup so they share the
-// strip's cache lines. Non-final pass: the result goes to T[b][line][role*M + k] through a
-// per-wave LDS transpose (coalesced stores), so the second launch of the same kernel
-// transforms the other axis. Final pass: squares are reduced per wave into partial sums.
-template <int M, int ROLE>
-__device__ __forceinline__ void split4_inputs(const float* col, int rs, float (&in)[M]) {
-  dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
-    constexpr int p = decltype(i)::value;
-    const float x0 = col[p * rs];
-    const float x1 = col[(2 * M - 1 - p) * rs];
-    const float x2 = col[(2 * M + p) * rs];
-    const float x3 = col[(4 * M - 1 - p) * rs];
-    if constexpr (ROLE == 0) {
-      in[p] = (x0 + x3) + (x1 + x2);
-    } else if constexpr (ROLE == 1) {
-      in[p] = (x0 + x3) - (x1 + x2);
+// k_pass1d transforms the row axis of In[b][n][line] (lines contiguous): one workgroup per
+// (<= 64-line strip), one wave per role; the strip is staged once with direct-to-LDS loads and
+// every role wave gathers its mirrored rows from LDS. Non-final pass: the result goes to
+// T[b][line][role*M + k] through a per-wave LDS transpose (coalesced stores), so the second launch
+// of the same kernel transforms the other axis. Final pass: squares are reduced per wave into
+// partial sums which k_split_reduce adds in fixed order.
+template <int N>
+struct SplitRoot {
+  static constexpr int len = N;
+  static constexpr bool is4 = false;
+  template <int J>
+  static __device__ __forceinline__ float in(const float* col, int rs) {
+    return col[J * rs];
+  }
+  static constexpr double wt(bool zero) { return zero ? 0.70710678118654752440 : 1.0; }  // global DC
+};
+
+template <class P, int WHICH>
+struct SplitNode {
+  static constexpr int len = P::len / 2;
+  static constexpr bool is4 = (!P::is4) && WHICH == 1;
+  template <int J>
+  static __device__ __forceinline__ float in(const float* col, int rs) {
+    const float y0 = P::template in<J>(col, rs);
+    const float y1 = P::template in<P::len - 1 - J>(col, rs);
+    if constexpr (!P::is4) {
+      return WHICH == 0 ? y0 + y1 : y0 - y1;
     } else {
-      constexpr float c = float(dcts::cospi_frac(2 * p + 1, 8 * M));
-      constexpr float sn = float(dcts::sinpi_frac(2 * p + 1, 8 * M));
-      const float d1 = x0 - x3, d2 = x1 - x2;
-      if constexpr (ROLE == 2) {
-        in[p] = d1 * c + d2 * sn;
+      constexpr float c = float(dcts::cospi_frac(2 * J + 1, 4 * P::len));
+      constexpr float sn = float(dcts::sinpi_frac(2 * J + 1, 4 * P::len));
+      if constexpr (WHICH == 0) {
+        return y0 * c + y1 * sn;
       } else {
-        constexpr float sg = (p % 2 == 0) ? 1.f : -1.f;
-        in[p] = d2 * (sg * c) - d1 * (sg * sn);
+        constexpr float sg = (J % 2 == 0) ? 1.f : -1.f;
+        return y1 * (sg * c) - y0 * (sg * sn);
       }
     }
-    // keep the scheduler from hoisting every LDS read to the top (register pressure -> spills);
-    // ALU work may still move across (mask: 1 ALU | 2 VALU | 4 SALU)
-    if constexpr (p % 8 == 7) __builtin_amdgcn_sched_barrier(7);
-  });
-}
-
-template <int M, int ROLE>
-__device__ __forceinline__ void split4_transform(const float (&in)[M], float (&out)[M]) {
-  if constexpr (ROLE == 1)
-    dcts::Dct4<M>::run(in, out);
-  else
-    dcts::Dct2<M>::run(in, out);
-  if constexpr (ROLE == 0) out[0] *= dcts::kInvSqrt2;  // DC of the whole axis
-  if constexpr (ROLE >= 2) {
-    constexpr float r2 = float(1.41421356237309504880168872420969808);
-    dcts::static_for<M - 1>([&](auto i) DCTS_LAMBDA_INLINE { out[decltype(i)::value + 1] *= r2; });
   }
-}
+  // amplitude weight of an output of this node; `zero`: its index in this node's output space is 0
+  static constexpr double wt(bool zero) {
+    const double f = (P::is4 && !zero) ? 1.41421356237309504880 : 1.0;
+    return f * P::wt(zero && WHICH == 0);
+  }
+};
 
-template <int M>
+template <int N, int L, int R>
+struct RoleLeaf {
+  using type = SplitNode<typename RoleLeaf<N, L - 1, (R >> 1)>::type, (R & 1)>;
+};
+template <int N>
+struct RoleLeaf<N, 0, 0> {
+  using type = SplitRoot<N>;
+};
+
+template <int M, int L>
 struct SplitCfg {
-  static constexpr int N = 4 * M;
+  static constexpr int N = M << L;
+  static constexpr int ROLES = 1 << L;
   static constexpr int STRIPS = (N + 63) / 64;
-  static constexpr int SW = (((N + STRIPS - 1) / STRIPS) + 3) / 4 * 4;  // lines per strip, multiple of 4
+  // lines per strip: 64 when rows are whole 128-byte lines (N % 32 == 0), so every staged row
+  // segment is two aligned cache lines (56-column strips of a 224-wide tile straddled lines:
+  // PMC showed 1.43x read over-fetch); otherwise balanced strips, multiple of 4
+  static constexpr int SW = (N % 32 == 0) ? 64 : (((N + STRIPS - 1) / STRIPS) + 3) / 4 * 4;
   static constexpr int SWP = SW | 1;                                    // odd LDS stride for the transpose
   static constexpr int IN_LDS = N * SW;                                 // floats: the staged input strip
-  static constexpr int TR_LDS = 4 * M * SWP;                            // floats: 4 per-wave transpose slabs
+  static constexpr int TR_LDS = ROLES * M * SWP;                        // floats: per-wave transpose slabs
   static constexpr int LDS_NONFINAL = IN_LDS > TR_LDS ? IN_LDS : TR_LDS;
 };
 
-// register budget (waves/SIMD) chosen so that no role spills
-template <int M>
-constexpr int split_waves_per_simd() { return M <= 32 ? 4 : (M <= 40 ? 3 : (M <= 56 ? 2 : 1)); }
+// The role butterflies as an in-place network on the 2^L mirrored samples of one (p, line):
+// slot s holds row s*M + p (s even) or s*M + M-1-p (s odd) of the strip. Level by level the
+// samples of a node are paired (index j with n-1-j), the pair is replaced by the inputs of the
+// node's two children, and after L levels every slot holds one input sample of one role. All
+// structure (which slots pair up, which role ends where, whether a role sees its samples in
+// ascending or descending p) is compile-time; only the rotation constants depend on p (table).
+template <int L>
+struct RolePlan {
+  static constexpr int S = 1 << L;
+  static constexpr int NOPS = L * (S / 2);
+  int op_a[NOPS > 0 ? NOPS : 1] = {}, op_b[NOPS > 0 ? NOPS : 1] = {}, op_rot[NOPS > 0 ? NOPS : 1] = {};
+  int nrot = 0;
+  int rot_seg[NOPS > 0 ? NOPS : 1] = {}, rot_asc[NOPS > 0 ? NOPS : 1] = {}, rot_c[NOPS > 0 ? NOPS : 1] = {};
+  int slot_of_role[S] = {}, asc_of_role[S] = {}, is4_of_role[S] = {};
+  constexpr RolePlan() {
+    int node[S] = {}, seg[S] = {}, asc[S] = {}, is4[S] = {};
+    for (int s = 0; s < S; ++s) {
+      seg[s] = s;
+      asc[s] = (s % 2 == 0) ? 1 : 0;
+    }
+    int c = S, n = 0;
+    for (int lvl = 0; lvl < L; ++lvl) {
+      int nnode[S] = {}, nis4[S] = {}, nseg[S] = {}, nasc[S] = {};
+      for (int i = 0; i < S; ++i) {
+        if (seg[i] >= c / 2) continue;
+        int k = -1;
+        for (int t = 0; t < S; ++t)
+          if (node[t] == node[i] && seg[t] == c - 1 - seg[i]) k = t;
+        op_a[n] = i;
+        op_b[n] = k;
+        if (is4[i]) {
+          op_rot[n] = nrot;
+          rot_seg[nrot] = seg[i];
+          rot_asc[nrot] = asc[i];
+          rot_c[nrot] = c;
+          ++nrot;
+        } else {
+          op_rot[n] = -1;
+        }
+        ++n;
+        nnode[i] = node[i] * 2;      // child 0 keeps the lower sample's slot
+        nnode[k] = node[i] * 2 + 1;  // child 1 takes the upper sample's slot
+        nis4[i] = 0;
+        nis4[k] = is4[i] ? 0 : 1;
+        nseg[i] = nseg[k] = seg[i];
+        nasc[i] = nasc[k] = asc[i];
+      }
+      for (int i = 0; i < S; ++i) {
+        node[i] = nnode[i];
+        is4[i] = nis4[i];
+        seg[i] = nseg[i];
+        asc[i] = nasc[i];
+      }
+      c /= 2;
+    }
+    for (int i = 0; i < S; ++i) {
+      slot_of_role[node[i]] = i;
+      asc_of_role[node[i]] = asc[i];
+      is4_of_role[node[i]] = is4[i];
+    }
+  }
+};
 
-template <int M, int ROLE, bool FINAL>
-__device__ __forceinline__ void split4_wave(const float* lds_in, float* __restrict__ t_b, float* lds_tr,
-                                            int strip, int lane, float* part) {
-  using Cfg = SplitCfg<M>;
+// rotation constants of the DCT-IV butterflies: for instance r and sample p the pair index is
+// j = seg*M + (asc ? p : M-1-p) inside a node of n = c*M points: cos/sin((2j+1) pi / (4n)), (-1)^j
+template <int M, int L>
+struct RotTable {
+  static constexpr int NR = (RolePlan<L>::NOPS > 0 ? RolePlan<L>::NOPS : 1);
+  float c[NR][M] = {}, s[NR][M] = {}, sg[NR][M] = {};
+  constexpr RotTable() {
+    constexpr RolePlan<L> plan{};
+    for (int r = 0; r < plan.nrot; ++r)
+      for (int p = 0; p < M; ++p) {
+        const int j = plan.rot_seg[r] * M + (plan.rot_asc[r] ? p : M - 1 - p);
+        const int n = plan.rot_c[r] * M;
+        c[r][p] = float(dcts::cospi_frac(2 * j + 1, 4 * n));
+        s[r][p] = float(dcts::sinpi_frac(2 * j + 1, 4 * n));
+        sg[r][p] = (j % 2 == 0) ? 1.f : -1.f;
+      }
+  }
+};
+template <int M, int L>
+__device__ const RotTable<M, L> kRotTable{};
+
+// register budget (waves/SIMD): the role waves only hold an M-point codelet
+template <int M>
+constexpr int split_waves_per_simd() { return M <= 32 ? 4 : (M <= 48 ? 3 : 2); }
+
+// role butterflies, in place: `base` is an LDS image [N rows][rs floats], lanes = columns
+template <int M, int L>
+__device__ __forceinline__ void split_butterflies(float* base, int rs, bool lane_ok, int lane, int wave) {
+  constexpr int S = 1 << L;
+  constexpr RolePlan<L> plan{};
+  const RotTable<M, L>& tab = kRotTable<M, L>;
+  float* colp = base + (lane_ok ? lane : 0);
+  for (int p = wave; p < M; p += S) {
+    float y[S];
+    dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int s = decltype(i)::value;
+      const int row = (s % 2 == 0) ? s * M + p : s * M + M - 1 - p;
+      y[s] = colp[row * rs];
+    });
+    dcts::static_for<plan.NOPS>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int o = decltype(i)::value;
+      constexpr int a = plan.op_a[o], bb = plan.op_b[o], r = plan.op_rot[o];
+      const float ya = y[a], yb = y[bb];
+      if constexpr (r < 0) {
+        y[a] = ya + yb;
+        y[bb] = ya - yb;
+      } else {
+        const float c = tab.c[r][p], sn = tab.s[r][p], sg = tab.sg[r][p];
+        y[a] = ya * c + yb * sn;
+        y[bb] = sg * (yb * c - ya * sn);
+      }
+    });
+    if (lane_ok) {
+      dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int s = decltype(i)::value;
+        const int row = (s % 2 == 0) ? s * M + p : s * M + M - 1 - p;
+        colp[row * rs] = y[s];
+      });
+    }
+  }
+}
+
+// role r's M-point transform of one column of the butterflied image: gathers the role's input
+// segment, runs the codelet, applies the role's amplitude weights
+template <int M, int L, int ROLE>
+__device__ __forceinline__ void split_role_transform(const float* col, int rs, float (&out)[M]) {
+  using Leaf = typename RoleLeaf<(M << L), L, ROLE>::type;
+  constexpr RolePlan<L> plan{};
+  constexpr int SLOT = plan.slot_of_role[ROLE];
+  constexpr bool ASC = plan.asc_of_role[ROLE] != 0;
+  static_assert(Leaf::len == M, "role tree depth");
+  static_assert((plan.is4_of_role[ROLE] != 0) == Leaf::is4, "role plan and role tree disagree");
+  float in[M];
+  dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int q = decltype(i)::value;   // index of the sample in the role's input
+    constexpr int p = ASC ? q : M - 1 - q;  // the (p, line) item that produced it
+    constexpr int row = (SLOT % 2 == 0) ? SLOT * M + p : SLOT * M + M - 1 - p;
+    in[q] = col[row * rs];
+  });
+  if constexpr (Leaf::is4)
+    dcts::Dct4<M>::run(in, out);
+  else
+    dcts::Dct2<M>::run(in, out);
+  constexpr float w0 = float(Leaf::wt(true)), w1 = float(Leaf::wt(false));
+  if constexpr (w0 != 1.0f) out[0] *= w0;
+  if constexpr (w1 != 1.0f)
+    dcts::static_for<M - 1>([&](auto i) DCTS_LAMBDA_INLINE { out[decltype(i)::value + 1] *= w1; });
+}
+
+template <int M, int L, int ROLE, bool FINAL>
+__device__ __forceinline__ void split_wave(const float* lds_in, float* __restrict__ t_b, float* lds_tr,
+                                           int strip, int lane, float* part) {
+  using Cfg = SplitCfg<M, L>;
   constexpr int N = Cfg::N, SW = Cfg::SW, SWP = Cfg::SWP;
   const int line = strip * SW + lane;
   const bool act = lane < SW && line < N;
-  float in[M], out[M];
-  split4_inputs<M, ROLE>(lds_in + (act ? lane : 0), SW, in);
-  split4_transform<M, ROLE>(in, out);
+  float out[M];
+  split_role_transform<M, L, ROLE>(lds_in + (act ? lane : 0), SW, out);
   if constexpr (FINAL) {
     float e = 0.f;
     dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
@@ -396,33 +554,49 @@ __device__ __forceinline__ void split4_wave(const float* lds_in, float* __restri
       const int k = k0 + lane;
       if (k < M) {
         float* dst = t_b + (long long)(strip * SW) * N + ROLE * M + k;
-#pragma unroll 8
-        for (int j = 0; j < nl; ++j) dst[(long long)j * N] = my[k * SWP + j];
+        const float* src = my + k * SWP;
+#pragma unroll 4
+        for (int j = 0; j < nl; ++j) {
+          *dst = src[j];
+          dst += N;
+        }
       }
     }
   }
 }
 
-// grid.x = nmaps_in_launch * STRIPS; block = 4 waves (wave = role).
-// The strip In[b][0..N)[strip*SW .. +SW) is staged into LDS by direct-to-LDS loads
-// (global_load_lds_dwordx4: no VGPRs, the whole 4*M*SW*4-byte strip in flight at once), then
-// each role wave gathers its four mirrored rows per sample from LDS.
-template <int M, bool FINAL>
-__global__ __launch_bounds__(256, (split_waves_per_simd<M>())) void k_pass1d(
+template <int M, int L, bool FINAL, int... R>
+__device__ __forceinline__ void split_dispatch(int role, const float* lds_in, float* t_b, float* lds_tr,
+                                               int strip, int lane, float* part,
+                                               std::integer_sequence<int, R...>) {
+  // exactly one branch is taken per wave (role is wave-uniform); every branch reaches the
+  // barrier inside split_wave, so the workgroup stays in step
+  ((role == R ? split_wave<M, L, R, FINAL>(lds_in, t_b, lds_tr, strip, lane, part) : (void)0), ...);
+}
+
+// grid.x = nmaps_in_launch * STRIPS; block = 2^L waves.
+//  1. the strip In[b][0..N)[strip*SW .. +SW) is staged into LDS by direct-to-LDS loads
+//     (global_load_lds_dwordx4: no VGPRs, the whole N*SW*4-byte strip in flight at once);
+//  2. role butterflies, in place in LDS: wave w takes the samples p = w, w + 2^L, ... of every
+//     line (lane = line): 2^L reads, L*2^(L-1) butterflies/rotations, 2^L writes per (p, line);
+//  3. wave r = role r: reads its M inputs (one contiguous segment of rows), M-point codelet,
+//     then the transposed store or the energy reduction.
+template <int M, int L, bool FINAL>
+__global__ __launch_bounds__((64 << L), (split_waves_per_simd<M>())) void k_pass1d(
     const float* __restrict__ in, long long in_map_stride, float* __restrict__ t, float* __restrict__ partial) {
-  using Cfg = SplitCfg<M>;
-  constexpr int N = Cfg::N, SW = Cfg::SW;
+  using Cfg = SplitCfg<M, L>;
+  constexpr int N = Cfg::N, SW = Cfg::SW, THREADS = 64 << L, S = Cfg::ROLES;
   __shared__ __attribute__((aligned(16))) float lds[FINAL ? Cfg::IN_LDS : Cfg::LDS_NONFINAL];
-  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long b = blockIdx.x / Cfg::STRIPS;
   const int strip = blockIdx.x - (int)(b * Cfg::STRIPS);
   const float* in_b = in + b * in_map_stride;
 
   constexpr int NQUADS = N * SW / 4;
-  constexpr int ITERS = (NQUADS + 255) / 256;
+  constexpr int ITERS = (NQUADS + THREADS - 1) / THREADS;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int qbase = it * 256 + role * 64;  // wave-uniform
+    const int qbase = it * THREADS + wave * 64;  // wave-uniform
     const int q = qbase + lane;
     const int e = 4 * q;
     const int row = e / SW, col = e - row * SW;
@@ -435,17 +609,155 @@ __global__ __launch_bounds__(256, (split_waves_per_simd<M>())) void k_pass1d(
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  split_butterflies<M, L>(lds, SW, lane < SW, lane, wave);
+  __syncthreads();
+
   float* t_b = FINAL ? nullptr : t + b * (long long)N * N;
-  float* part = partial + (long long)blockIdx.x * 4 + role;
-  switch (role) {
-    case 0: split4_wave<M, 0, FINAL>(lds, t_b, lds, strip, lane, part); break;
-    case 1: split4_wave<M, 1, FINAL>(lds, t_b, lds, strip, lane, part); break;
-    case 2: split4_wave<M, 2, FINAL>(lds, t_b, lds, strip, lane, part); break;
-    default: split4_wave<M, 3, FINAL>(lds, t_b, lds, strip, lane, part); break;
+  float* part = partial + (long long)blockIdx.x * Cfg::ROLES + wave;
+  split_dispatch<M, L, FINAL>(wave, lds, t_b, lds, strip, lane, part,
+                              std::make_integer_sequence<int, Cfg::ROLES>{});
+}
+
+// ---------------------------------------------------------------------------------------
+// fused split kernel: one launch, HBM traffic = the input, for tiles the register file can park
+// ---------------------------------------------------------------------------------------
+// One persistent workgroup (2^L role waves) per CU walks over maps. Pass 1 as in k_pass1d, strip
+// by strip (64 columns, double-buffered direct-to-LDS staging: strip s+1 streams in while strip s
+// is transformed), but the role outputs are not written out: wave q keeps T[line][q*M + k] for
+// all its lines in VGPRs (STRIPS*M registers per lane: the whole N x N intermediate tile lives in
+// the register file). Pass 2 runs in rounds of RPR role groups: their waves dump the parked rows
+// into LDS as an image [line][kk], the role butterflies run in place along the lines, every
+// wave runs one W-role codelet with lane = kk, and the squares are accumulated.
+template <int M, int L>
+struct FusedCfg {
+  static constexpr int N = M << L;
+  static constexpr int S = 1 << L;
+  static constexpr int SW = 64;
+  static constexpr int STRIPS = (N + SW - 1) / SW;
+  static constexpr int RPR = (64 / M) >= 2 ? 2 : 1;  // role groups per pass-2 round (lanes = RPR*M)
+  static constexpr int ROUNDS = S / RPR;
+  static constexpr int RW = (RPR * M) | 1;           // pass-2 image row stride (odd: conflict-free dump)
+  static constexpr int BUF = (N * SW > N * RW ? N * SW : N * RW);  // floats per LDS buffer
+  static_assert(N % 4 == 0 && S % RPR == 0, "shape");
+};
+
+template <int M, int L>
+__device__ __forceinline__ void fused_stage(const float* __restrict__ in_b, int strip, float* buf, int lane,
+                                            int wave) {
+  using Cfg = FusedCfg<M, L>;
+  constexpr int N = Cfg::N, SW = Cfg::SW, THREADS = 64 << L;
+  constexpr int NQUADS = N * SW / 4;
+  constexpr int ITERS = (NQUADS + THREADS - 1) / THREADS;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int qbase = it * THREADS + wave * 64;  // wave-uniform
+    const int q = qbase + lane;
+    const int e = 4 * q;
+    const int row = e / SW, col = e - row * SW;
+    if (q < NQUADS && strip * SW + col < N) {
+      const float* g = in_b + (long long)row * N + strip * SW + col;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(buf + 4 * qbase), 16, 0, 0);
+    }
   }
 }
 
-// out[b] = scale * sum of the map's 4*STRIPS partials, fixed order
+template <int M, int L, int ROLE>
+__device__ __forceinline__ void fused_body(const float* __restrict__ x, long long map_stride, long long nmaps,
+                                           float* __restrict__ out, float* lds, float* partials, int lane) {
+  using Cfg = FusedCfg<M, L>;
+  constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, STRIPS = Cfg::STRIPS, RPR = Cfg::RPR,
+                ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, BUF = Cfg::BUF;
+  int cur = 0;
+  long long m = blockIdx.x;
+  if (m < nmaps) fused_stage<M, L>(x + m * map_stride, 0, lds, lane, ROLE);
+  for (; m < nmaps; m += gridDim.x) {
+    const float* in_b = x + m * map_stride;
+    float parked[STRIPS][M];
+    // ---- pass 1: H axis, strip by strip -------------------------------------------------
+    dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
+      constexpr int s = decltype(is)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this strip has landed
+      __syncthreads();                                   // ... for everyone; the other buffer is free
+      float* buf = lds + cur * BUF;
+      float* nxt = lds + (cur ^ 1) * BUF;
+      if constexpr (s + 1 < STRIPS) {
+        fused_stage<M, L>(in_b, s + 1, nxt, lane, ROLE);
+      } else {
+        if (m + gridDim.x < nmaps) fused_stage<M, L>(x + (m + gridDim.x) * map_stride, 0, nxt, lane, ROLE);
+      }
+      const bool act = s * SW + lane < N;  // lane < 64 == SW always
+      split_butterflies<M, L>(buf, SW, act, lane, ROLE);
+      __syncthreads();
+      split_role_transform<M, L, ROLE>(buf + (act ? lane : 0), SW, parked[s]);
+      cur ^= 1;
+    });
+    // ---- pass 2: W axis, RPR role groups of parked rows per round ---------------------------
+    float* blk = lds + (cur ^ 1) * BUF;  // the last strip's buffer; the other one is receiving
+    float e = 0.f;
+    dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
+      constexpr int r = decltype(ir)::value;
+      __syncthreads();  // previous readers of blk are done
+      if constexpr (ROLE / RPR == r) {
+        constexpr int c0 = (ROLE % RPR) * M;
+        dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
+          constexpr int s = decltype(is)::value;
+          const int line = s * SW + lane;
+          if (line < N) {
+            float* dst = blk + line * RW + c0;
+            dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+              constexpr int k = decltype(ik)::value;
+              dst[k] = parked[s][k];
+            });
+          }
+        });
+      }
+      __syncthreads();
+      const bool act = lane < RPR * M;
+      split_butterflies<M, L>(blk, RW, act, lane, ROLE);
+      __syncthreads();
+      float o[M];
+      split_role_transform<M, L, ROLE>(blk + (act ? lane : 0), RW, o);
+      float er = 0.f;
+      dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+        constexpr int k = decltype(ik)::value;
+        er = fmaf(o[k], o[k], er);
+      });
+      if (act) e += er;
+    });
+    // ---- reduce: lanes -> wave -> workgroup, fixed order -------------------------------------
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e += __shfl_down(e, off, 64);
+    if (lane == 0) partials[ROLE] = e;
+    __syncthreads();
+    if (ROLE == 0 && lane == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < S; ++i) t += partials[i];
+      constexpr float sc = float(4.0 / (double(N) * double(N)));
+      out[m] = t * sc;
+    }
+  }
+}
+
+template <int M, int L, int... R>
+__device__ __forceinline__ void fused_dispatch(int role, const float* x, long long map_stride, long long nmaps,
+                                               float* out, float* lds, float* partials, int lane,
+                                               std::integer_sequence<int, R...>) {
+  ((role == R ? fused_body<M, L, R>(x, map_stride, nmaps, out, lds, partials, lane) : (void)0), ...);
+}
+
+template <int M, int L>
+__global__ __launch_bounds__((64 << L), 2) void k_split_fused(const float* __restrict__ x, long long map_stride,
+                                                              long long nmaps, float* __restrict__ out) {
+  using Cfg = FusedCfg<M, L>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF];
+  __shared__ float partials[Cfg::S];
+  fused_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, lds, partials, threadIdx.x & 63,
+                       std::make_integer_sequence<int, Cfg::S>{});
+}
+
+// out[b] = scale * sum of the map's ROLES*STRIPS partials, fixed order
 __global__ void k_split_reduce(const float* __restrict__ partial, int per_map, long long nmaps,
                                float scale, float* __restrict__ out) {
   const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -757,16 +1069,27 @@ int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipS
 #undef DCTS_CASE
 }
 
-// tile edges N = 4*M served by the split-4 family
-#define DCTS_SPLIT_M(X) X(18) X(20) X(28) X(32) X(36) X(40) X(56) X(64) X(72) X(80)
+// tile edges served by the split family: X(N, M, L) with N = M << L. L = 3 (eight M-point roles)
+// where the four-role codelets would be too register-hungry for more than 1-2 waves per SIMD.
+#define DCTS_SPLIT_TABLE(X)                                                              \
+  X(72, 18, 2) X(80, 20, 2) X(112, 28, 2) X(128, 32, 2) X(144, 36, 2) X(160, 40, 2)      \
+  X(224, 28, 3) X(256, 32, 3) X(288, 36, 3) X(320, 40, 3)
 
 bool has_split(long long HP, long long WP) {
   if (HP != WP) return false;
-#define DCTS_CASE(M_) \
-  if (HP == 4 * M_) return true;
-  DCTS_SPLIT_M(DCTS_CASE)
+#define DCTS_CASE(N_, M_, L_) \
+  if (HP == N_) return true;
+  DCTS_SPLIT_TABLE(DCTS_CASE)
 #undef DCTS_CASE
   return false;
+}
+
+int split_partials_per_map(int N) {
+#define DCTS_CASE(N_, M_, L_) \
+  if (N == N_) return SplitCfg<M_, L_>::STRIPS * SplitCfg<M_, L_>::ROLES;
+  DCTS_SPLIT_TABLE(DCTS_CASE)
+#undef DCTS_CASE
+  return 0;
 }
 
 // intermediate tile buffer per launch pair; DCTS_SPLIT_CHUNK_MB overrides (tuning knob)
@@ -791,16 +1114,15 @@ SplitWs split_ws(long long nmaps, int N) {
   if (chunk < 1) chunk = 1;
   if (chunk > nmaps) chunk = nmaps;
   w.chunk_maps = chunk;
-  const int strips = (N + 63) / 64;
   w.off_t = 0;
   w.off_part = align_up((size_t)chunk * map_bytes, 256);
-  w.total = align_up(w.off_part + (size_t)chunk * strips * 4 * 4, 256);
+  w.total = align_up(w.off_part + (size_t)chunk * split_partials_per_map(N) * 4, 256);
   return w;
 }
 
-template <int M>
+template <int M, int L>
 int launch_split(const MapGeom& g, float* out, void* workspace, hipStream_t st) {
-  using Cfg = SplitCfg<M>;
+  using Cfg = SplitCfg<M, L>;
   constexpr int N = Cfg::N;
   const SplitWs ws = split_ws(g.nmaps, N);
   char* wsp = reinterpret_cast<char*>(workspace);
@@ -811,22 +1133,54 @@ int launch_split(const MapGeom& g, float* out, void* workspace, hipStream_t st) 
   for (long long m0 = 0; m0 < g.nmaps; m0 += ws.chunk_maps) {
     const long long nb = (g.nmaps - m0) < ws.chunk_maps ? (g.nmaps - m0) : ws.chunk_maps;
     const unsigned grid = (unsigned)(nb * Cfg::STRIPS);
-    hipLaunchKernelGGL((k_pass1d<M, false>), dim3(grid), dim3(256), 0, st, x0 + m0 * g.strideC, g.strideC, T,
-                       part);
-    hipLaunchKernelGGL((k_pass1d<M, true>), dim3(grid), dim3(256), 0, st, T, (long long)N * N, (float*)nullptr,
-                       part);
+    hipLaunchKernelGGL((k_pass1d<M, L, false>), dim3(grid), dim3(64 << L), 0, st, x0 + m0 * g.strideC,
+                       g.strideC, T, part);
+    hipLaunchKernelGGL((k_pass1d<M, L, true>), dim3(grid), dim3(64 << L), 0, st, T, (long long)N * N,
+                       (float*)nullptr, part);
     hipLaunchKernelGGL(k_split_reduce, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, part,
-                       Cfg::STRIPS * 4, nb, scale, out + m0);
+                       Cfg::STRIPS * Cfg::ROLES, nb, scale, out + m0);
   }
   return (int)hipGetLastError();
 }
 
-int dispatch_split(int N, const MapGeom& g, float* out, void* workspace, hipStream_t st) {
-#define DCTS_CASE(M_) \
-  case 4 * M_:        \
-    return launch_split<M_>(g, out, workspace, st);
+// tiles whose intermediate fits the register file of one CU: single fused launch
+#define DCTS_FUSED_TABLE(X) X(224, 28, 3) X(256, 32, 3)
+
+bool has_fused(long long N) {
+#define DCTS_CASE(N_, M_, L_) \
+  if (N == N_) return true;
+  DCTS_FUSED_TABLE(DCTS_CASE)
+#undef DCTS_CASE
+  return false;
+}
+
+template <int M, int L>
+int launch_fused(const MapGeom& g, float* out, hipStream_t st) {
+  const float* x0 = g.x + (long long)g.c_begin * g.strideC;
+  long long grid = g.nmaps < kNumCU ? g.nmaps : kNumCU;  // one workgroup per CU (LDS-limited)
+  hipLaunchKernelGGL((k_split_fused<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, x0, g.strideC, g.nmaps,
+                     out);
+  return (int)hipGetLastError();
+}
+
+int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
+#define DCTS_CASE(N_, M_, L_) \
+  case N_:                    \
+    return launch_fused<M_, L_>(g, out, st);
   switch (N) {
-    DCTS_SPLIT_M(DCTS_CASE)
+    DCTS_FUSED_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+
+int dispatch_split(int N, const MapGeom& g, float* out, void* workspace, hipStream_t st) {
+#define DCTS_CASE(N_, M_, L_) \
+  case N_:                    \
+    return launch_split<M_, L_>(g, out, workspace, st);
+  switch (N) {
+    DCTS_SPLIT_TABLE(DCTS_CASE)
     default:
       return DCTS_E_UNSUPPORTED;
   }
@@ -873,7 +1227,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
   if ((algo == DCTS_ALGO_CODELET || algo == DCTS_ALGO_PREFETCH) && !codelet_ok) return DCTS_E_UNSUPPORTED;
   if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET &&
-      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH)
+      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED)
     return DCTS_E_UNSUPPORTED;
   if (codelet_ok && algo != DCTS_ALGO_DIRECT) {
     if constexpr (!STORE) {
@@ -892,13 +1246,17 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     const bool split_ok = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous &&
                           strideC == H * W;
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
+    const bool fused_ok = split_ok && has_fused(HP) &&
+                          (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
+    if (algo == DCTS_ALGO_FUSED && !fused_ok) return DCTS_E_UNSUPPORTED;
+    if (fused_ok && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED)) return dispatch_fused((int)HP, g, out, st);
     if (split_ok && algo != DCTS_ALGO_DIRECT) {
       const SplitWs sws = split_ws(g.nmaps, (int)HP);
       if (!workspace || workspace_bytes < sws.total) return DCTS_E_WORKSPACE;
       return dispatch_split((int)HP, g, out, workspace, st);
     }
   } else {
-    if (algo == DCTS_ALGO_SPLIT) return DCTS_E_UNSUPPORTED;
+    if (algo == DCTS_ALGO_SPLIT || algo == DCTS_ALGO_FUSED) return DCTS_E_UNSUPPORTED;
   }
 
   const DirectWs ws = direct_ws(g.nmaps, (int)HP, (int)WP);

@@ -57,8 +57,10 @@ enum {
   DCTS_ALGO_DIRECT = 1,   /* cosine-basis-in-LDS separable kernel, any (H, W) <= DCTS_MAX_EDGE   */
   DCTS_ALGO_CODELET = 2,  /* register-resident factorised DCT codelets (selected tile sizes)     */
   DCTS_ALGO_SPLIT = 3,    /* two-launch split-4 codelet passes for edges 4*M (72 ... 320)        */
-  DCTS_ALGO_PREFETCH = 4  /* codelet kernel with direct-to-LDS prefetch of the next maps (dense,
+  DCTS_ALGO_PREFETCH = 4, /* codelet kernel with direct-to-LDS prefetch of the next maps (dense,
                              even-edge square tiles; measured equal to ALGO_CODELET, opt-in)     */
+  DCTS_ALGO_FUSED = 5     /* single-launch split kernel, intermediate tile parked in VGPRs
+                             (224x224, 256x256)                                                  */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */

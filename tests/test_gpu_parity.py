@@ -76,9 +76,25 @@ def test_split_sizes(n):
     x = synth(2, 11, n, n, 30 + n)
     got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_SPLIT)
     check(x, got)
-    assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks the same kernels
+    if n not in (224, 256):
+        assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks the same kernels
     ref = orc.energy_nc(x[:1, :2])
     assert rel_err(got[:1, :2].cpu(), ref) <= RTOL
+
+
+@pytest.mark.parametrize("n", [224, 256])
+def test_fused_sizes(n):
+    """Single-launch split kernel (intermediate tile parked in VGPRs): more maps than workgroups so
+    every workgroup loops and the double-buffered staging wraps around."""
+    x = synth(2, 150, n, n, 130 + n)
+    got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_FUSED)
+    check(x, got)
+    assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
+    assert torch.equal(got, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_FUSED))  # bit-reproducible
+    two = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_SPLIT)
+    assert rel_err(got.cpu(), two.cpu()) <= 1e-5
+    few = synth(1, 3, n, n, 131 + n)  # fewer maps than workgroups
+    check(few, dpa.energy_nc(few.cuda(), algo=dpa.ALGO_FUSED))
 
 
 def test_split_chunking_many_maps():
