@@ -453,13 +453,19 @@ __device__ const RotTable<M, L> kRotTable{};
 template <int M>
 constexpr int split_waves_per_simd() { return M <= 32 ? 4 : (M <= 48 ? 3 : 2); }
 
+// LDS pointers stay in address space 3 end to end: a generic pointer handed through these helpers
+// needs a flat->local cast (with a null check) at every use, which ROCm 7.2's gfx950 backend
+// mis-selects inside the fused kernel ("V_CMP_NE_U32 0, $src_shared_base": illegal instruction)
+using lds_ptr = __attribute__((address_space(3))) float*;
+using lds_cptr = const __attribute__((address_space(3))) float*;
+
 // role butterflies, in place: `base` is an LDS image [N rows][rs floats], lanes = columns
 template <int M, int L>
-__device__ __forceinline__ void split_butterflies(float* base, int rs, bool lane_ok, int lane, int wave) {
+__device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lane_ok, int lane, int wave) {
   constexpr int S = 1 << L;
   constexpr RolePlan<L> plan{};
   const RotTable<M, L>& tab = kRotTable<M, L>;
-  float* colp = base + (lane_ok ? lane : 0);
+  lds_ptr colp = base + (lane_ok ? lane : 0);
   for (int p = wave; p < M; p += S) {
     float y[S];
     dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
@@ -493,7 +499,7 @@ __device__ __forceinline__ void split_butterflies(float* base, int rs, bool lane
 // role r's M-point transform of one column of the butterflied image: gathers the role's input
 // segment, runs the codelet, applies the role's amplitude weights
 template <int M, int L, int ROLE>
-__device__ __forceinline__ void split_role_transform(const float* col, int rs, float (&out)[M]) {
+__device__ __forceinline__ void split_role_transform(lds_cptr col, int rs, float (&out)[M]) {
   using Leaf = typename RoleLeaf<(M << L), L, ROLE>::type;
   constexpr RolePlan<L> plan{};
   constexpr int SLOT = plan.slot_of_role[ROLE];
@@ -518,7 +524,7 @@ __device__ __forceinline__ void split_role_transform(const float* col, int rs, f
 }
 
 template <int M, int L, int ROLE, bool FINAL>
-__device__ __forceinline__ void split_wave(const float* lds_in, float* __restrict__ t_b, float* lds_tr,
+__device__ __forceinline__ void split_wave(lds_cptr lds_in, float* __restrict__ t_b, lds_ptr lds_tr,
                                            int strip, int lane, float* part) {
   using Cfg = SplitCfg<M, L>;
   constexpr int N = Cfg::N, SW = Cfg::SW, SWP = Cfg::SWP;
@@ -538,7 +544,7 @@ __device__ __forceinline__ void split_wave(const float* lds_in, float* __restric
     if (lane == 0) *part = e;
   } else {
     __syncthreads();  // every wave has consumed the staged strip: its LDS becomes the transpose slabs
-    float* my = lds_tr + ROLE * (M * SWP);
+    lds_ptr my = lds_tr + ROLE * (M * SWP);
     if (act) {
       dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE {
         constexpr int k = decltype(i)::value;
@@ -554,7 +560,7 @@ __device__ __forceinline__ void split_wave(const float* lds_in, float* __restric
       const int k = k0 + lane;
       if (k < M) {
         float* dst = t_b + (long long)(strip * SW) * N + ROLE * M + k;
-        const float* src = my + k * SWP;
+        lds_cptr src = my + k * SWP;
 #pragma unroll 4
         for (int j = 0; j < nl; ++j) {
           *dst = src[j];
@@ -566,7 +572,7 @@ __device__ __forceinline__ void split_wave(const float* lds_in, float* __restric
 }
 
 template <int M, int L, bool FINAL, int... R>
-__device__ __forceinline__ void split_dispatch(int role, const float* lds_in, float* t_b, float* lds_tr,
+__device__ __forceinline__ void split_dispatch(int role, lds_cptr lds_in, float* t_b, lds_ptr lds_tr,
                                                int strip, int lane, float* part,
                                                std::integer_sequence<int, R...>) {
   // exactly one branch is taken per wave (role is wave-uniform); every branch reaches the
@@ -609,12 +615,13 @@ __global__ __launch_bounds__((64 << L), (split_waves_per_simd<M>())) void k_pass
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  split_butterflies<M, L>(lds, SW, lane < SW, lane, wave);
+  const lds_ptr lds3 = (lds_ptr)lds;
+  split_butterflies<M, L>(lds3, SW, lane < SW, lane, wave);
   __syncthreads();
 
   float* t_b = FINAL ? nullptr : t + b * (long long)N * N;
   float* part = partial + (long long)blockIdx.x * Cfg::ROLES + wave;
-  split_dispatch<M, L, FINAL>(wave, lds, t_b, lds, strip, lane, part,
+  split_dispatch<M, L, FINAL>(wave, lds3, t_b, lds3, strip, lane, part,
                               std::make_integer_sequence<int, Cfg::ROLES>{});
 }
 
@@ -625,24 +632,31 @@ __global__ __launch_bounds__((64 << L), (split_waves_per_simd<M>())) void k_pass
 // by strip (64 columns, double-buffered direct-to-LDS staging: strip s+1 streams in while strip s
 // is transformed), but the role outputs are not written out: wave q keeps T[line][q*M + k] for
 // all its lines in VGPRs (STRIPS*M registers per lane: the whole N x N intermediate tile lives in
-// the register file). Pass 2 runs in rounds of RPR role groups: their waves dump the parked rows
-// into LDS as an image [line][kk], the role butterflies run in place along the lines, every
-// wave runs one W-role codelet with lane = kk, and the squares are accumulated.
+// the register file). Pass 2 runs in rounds of 56-64 coefficient columns (KPR from every role):
+// the waves dump those parked rows into LDS as an image [line][column], the role butterflies
+// run in place along the lines, every wave runs one W-role codelet with lane = column, and the
+// squares are accumulated.
 template <int M, int L>
 struct FusedCfg {
   static constexpr int N = M << L;
   static constexpr int S = 1 << L;
   static constexpr int SW = 64;
   static constexpr int STRIPS = (N + SW - 1) / SW;
-  static constexpr int RPR = (64 / M) >= 2 ? 2 : 1;  // role groups per pass-2 round (lanes = RPR*M)
-  static constexpr int ROUNDS = S / RPR;
-  static constexpr int RW = (RPR * M) | 1;           // pass-2 image row stride (odd: conflict-free dump)
+  static constexpr int RPR = (64 / M) >= 2 ? 2 : 1;          // role groups that fit the 64 lanes
+  static constexpr int COLS = RPR * M;                       // pass-2 columns (lanes) per round
+  // which parked rows go into a round: BALANCED = KPR coefficients of EVERY role (all waves dump,
+  // equal work; every wave keeps its whole parked set live until the last round) or, where that
+  // costs spills (M = 28: 112 parked + the codelet > 256 VGPRs), RPR whole roles per round
+  static constexpr bool BALANCED = (M == 32);
+  static constexpr int KPR = COLS / S;
+  static constexpr int ROUNDS = BALANCED ? M / KPR : S / RPR;
+  static constexpr int RW = COLS | 1;                        // pass-2 image row stride (odd: conflict-free dump)
   static constexpr int BUF = (N * SW > N * RW ? N * SW : N * RW);  // floats per LDS buffer
-  static_assert(N % 4 == 0 && S % RPR == 0, "shape");
+  static_assert(N % 4 == 0 && S % RPR == 0 && (!BALANCED || (COLS % S == 0 && M % KPR == 0)), "shape");
 };
 
 template <int M, int L>
-__device__ __forceinline__ void fused_stage(const float* __restrict__ in_b, int strip, float* buf, int lane,
+__device__ __forceinline__ void fused_stage(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
                                             int wave) {
   using Cfg = FusedCfg<M, L>;
   constexpr int N = Cfg::N, SW = Cfg::SW, THREADS = 64 << L;
@@ -664,10 +678,10 @@ __device__ __forceinline__ void fused_stage(const float* __restrict__ in_b, int 
 
 template <int M, int L, int ROLE>
 __device__ __forceinline__ void fused_body(const float* __restrict__ x, long long map_stride, long long nmaps,
-                                           float* __restrict__ out, float* lds, float* partials, int lane) {
+                                           float* __restrict__ out, lds_ptr lds, lds_ptr partials, int lane) {
   using Cfg = FusedCfg<M, L>;
-  constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, STRIPS = Cfg::STRIPS, RPR = Cfg::RPR,
-                ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, BUF = Cfg::BUF;
+  constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, STRIPS = Cfg::STRIPS, COLS = Cfg::COLS, KPR = Cfg::KPR,
+                RPR = Cfg::RPR, ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, BUF = Cfg::BUF;
   int cur = 0;
   long long m = blockIdx.x;
   if (m < nmaps) fused_stage<M, L>(x + m * map_stride, 0, lds, lane, ROLE);
@@ -679,8 +693,8 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       constexpr int s = decltype(is)::value;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this strip has landed
       __syncthreads();                                   // ... for everyone; the other buffer is free
-      float* buf = lds + cur * BUF;
-      float* nxt = lds + (cur ^ 1) * BUF;
+      const lds_ptr buf = lds + cur * BUF;
+      const lds_ptr nxt = lds + (cur ^ 1) * BUF;
       if constexpr (s + 1 < STRIPS) {
         fused_stage<M, L>(in_b, s + 1, nxt, lane, ROLE);
       } else {
@@ -693,27 +707,34 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       cur ^= 1;
     });
     // ---- pass 2: W axis, RPR role groups of parked rows per round ---------------------------
-    float* blk = lds + (cur ^ 1) * BUF;  // the last strip's buffer; the other one is receiving
+    const lds_ptr blk = lds + (cur ^ 1) * BUF;  // the last strip's buffer; the other one is receiving
     float e = 0.f;
     dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(ir)::value;
       __syncthreads();  // previous readers of blk are done
-      if constexpr (ROLE / RPR == r) {
-        constexpr int c0 = (ROLE % RPR) * M;
+      if constexpr (Cfg::BALANCED) {
         dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
           constexpr int s = decltype(is)::value;
           const int line = s * SW + lane;
-          if (line < N) {
-            float* dst = blk + line * RW + c0;
-            dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
-              constexpr int k = decltype(ik)::value;
-              dst[k] = parked[s][k];
-            });
-          }
+          const int off = (line < N ? line : 0) * RW + ROLE * KPR;
+          dcts::static_for<KPR>([&](auto ik) DCTS_LAMBDA_INLINE {
+            constexpr int k = decltype(ik)::value;
+            if (line < N) blk[off + k] = parked[s][r * KPR + k];
+          });
+        });
+      } else if constexpr (ROLE / RPR == r) {
+        dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
+          constexpr int s = decltype(is)::value;
+          const int line = s * SW + lane;
+          const int off = (line < N ? line : 0) * RW + (ROLE % RPR) * M;
+          dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+            constexpr int k = decltype(ik)::value;
+            if (line < N) blk[off + k] = parked[s][k];
+          });
         });
       }
       __syncthreads();
-      const bool act = lane < RPR * M;
+      const bool act = lane < COLS;
       split_butterflies<M, L>(blk, RW, act, lane, ROLE);
       __syncthreads();
       float o[M];
@@ -742,7 +763,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
 
 template <int M, int L, int... R>
 __device__ __forceinline__ void fused_dispatch(int role, const float* x, long long map_stride, long long nmaps,
-                                               float* out, float* lds, float* partials, int lane,
+                                               float* out, lds_ptr lds, lds_ptr partials, int lane,
                                                std::integer_sequence<int, R...>) {
   ((role == R ? fused_body<M, L, R>(x, map_stride, nmaps, out, lds, partials, lane) : (void)0), ...);
 }
@@ -753,7 +774,7 @@ __global__ __launch_bounds__((64 << L), 2) void k_split_fused(const float* __res
   using Cfg = FusedCfg<M, L>;
   __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF];
   __shared__ float partials[Cfg::S];
-  fused_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, lds, partials, threadIdx.x & 63,
+  fused_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63,
                        std::make_integer_sequence<int, Cfg::S>{});
 }
 
