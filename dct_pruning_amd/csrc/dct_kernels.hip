@@ -460,8 +460,16 @@ using lds_ptr = __attribute__((address_space(3))) float*;
 using lds_cptr = const __attribute__((address_space(3))) float*;
 
 // role butterflies, in place: `base` is an LDS image [N rows][rs floats], lanes = columns
-template <int M, int L>
-__device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lane_ok, int lane, int wave) {
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// `hook` runs once per sample iteration: the fused kernel uses it to trickle out the direct-to-LDS
+// loads of the next strip between butterflies instead of issuing them in one burst (a burst of
+// 8 x 8 KiB per CU back-pressures the issue: stamps showed 470 cycles per load instruction)
+template <int M, int L, class Hook = NoHook>
+__device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lane_ok, int lane, int wave,
+                                                  Hook hook = Hook{}) {
   constexpr int S = 1 << L;
   constexpr RolePlan<L> plan{};
   const RotTable<M, L>& tab = kRotTable<M, L>;
@@ -493,6 +501,7 @@ __device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lan
         colp[row * rs] = y[s];
       });
     }
+    hook();
   }
 }
 
@@ -655,26 +664,49 @@ struct FusedCfg {
   static_assert(N % 4 == 0 && S % RPR == 0 && (!BALANCED || (COLS % S == 0 && M % KPR == 0)), "shape");
 };
 
+// one direct-to-LDS instruction (64 lanes x 16 B) of a strip's staging: piece `it` of PIECES.
+// lane q = it*THREADS + wave*64 + lane covers row q/16, columns 4*(q%16).. of the 64-wide strip
 template <int M, int L>
-__device__ __forceinline__ void fused_stage(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
-                                            int wave) {
+struct FusedStage {
   using Cfg = FusedCfg<M, L>;
-  constexpr int N = Cfg::N, SW = Cfg::SW, THREADS = 64 << L;
-  constexpr int NQUADS = N * SW / 4;
-  constexpr int ITERS = (NQUADS + THREADS - 1) / THREADS;
-#pragma unroll
-  for (int it = 0; it < ITERS; ++it) {
+  static constexpr int N = Cfg::N, SW = Cfg::SW, THREADS = 64 << L;
+  static constexpr int NQUADS = N * SW / 4;
+  static constexpr int PIECES = (NQUADS + THREADS - 1) / THREADS;
+  static_assert(SW == 64, "piece addressing assumes 16 quads per row");
+  static __device__ __forceinline__ void piece(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
+                                               int wave, int it) {
     const int qbase = it * THREADS + wave * 64;  // wave-uniform
     const int q = qbase + lane;
-    const int e = 4 * q;
-    const int row = e / SW, col = e - row * SW;
+    const int row = q >> 4, col = (q & 15) << 2;
     if (q < NQUADS && strip * SW + col < N) {
       const float* g = in_b + (long long)row * N + strip * SW + col;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(buf + 4 * qbase), 16, 0, 0);
     }
   }
-}
+  static __device__ __forceinline__ void all(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
+                                             int wave) {
+#pragma unroll
+    for (int it = 0; it < PIECES; ++it) piece(in_b, strip, buf, lane, wave, it);
+  }
+};
+
+// Diagnostic build only (-DDCTS_FUSED_STAMPS, tools/stamp_fused.sh): s_memtime stamps at the phase
+// boundaries of the fused kernel, summed per wave into g_fused_stamps (never touches an output).
+#ifdef DCTS_FUSED_STAMPS
+__device__ unsigned long long g_fused_stamps[8][16];
+#define DCTS_STAMP(slot)                                                          \
+  do {                                                                            \
+    unsigned long long t_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    acc_[slot] += t_ - last_;                                                     \
+    last_ = t_;                                                                   \
+  } while (0)
+#else
+#define DCTS_STAMP(slot) ((void)0)
+#endif
 
 template <int M, int L, int ROLE>
 __device__ __forceinline__ void fused_body(const float* __restrict__ x, long long map_stride, long long nmaps,
@@ -684,26 +716,44 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
                 RPR = Cfg::RPR, ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, BUF = Cfg::BUF;
   int cur = 0;
   long long m = blockIdx.x;
-  if (m < nmaps) fused_stage<M, L>(x + m * map_stride, 0, lds, lane, ROLE);
+#ifdef DCTS_FUSED_STAMPS
+  unsigned long long acc_[16] = {}, last_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
+  if (m < nmaps) FusedStage<M, L>::all(x + m * map_stride, 0, lds, lane, ROLE);
   for (; m < nmaps; m += gridDim.x) {
     const float* in_b = x + m * map_stride;
     float parked[STRIPS][M];
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
       constexpr int s = decltype(is)::value;
+      DCTS_STAMP(11);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this strip has landed
+      DCTS_STAMP(0);
       __syncthreads();                                   // ... for everyone; the other buffer is free
+      DCTS_STAMP(1);
       const lds_ptr buf = lds + cur * BUF;
       const lds_ptr nxt = lds + (cur ^ 1) * BUF;
-      if constexpr (s + 1 < STRIPS) {
-        fused_stage<M, L>(in_b, s + 1, nxt, lane, ROLE);
-      } else {
-        if (m + gridDim.x < nmaps) fused_stage<M, L>(x + (m + gridDim.x) * map_stride, 0, nxt, lane, ROLE);
-      }
+      // the next strip (or the next map's first one) streams into the other buffer while this one
+      // is transformed; its load instructions are trickled out between the butterflies
+      const bool more = (s + 1 < STRIPS) || (m + gridDim.x < nmaps);
+      const float* nsrc = (s + 1 < STRIPS) ? in_b : x + (m + gridDim.x) * map_stride;
+      constexpr int nstrip = (s + 1 < STRIPS) ? s + 1 : 0;
+      int piece = more ? 0 : FusedStage<M, L>::PIECES;
+      auto trickle = [&]() DCTS_LAMBDA_INLINE {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (piece < FusedStage<M, L>::PIECES) FusedStage<M, L>::piece(nsrc, nstrip, nxt, lane, ROLE, piece++);
+      };
       const bool act = s * SW + lane < N;  // lane < 64 == SW always
-      split_butterflies<M, L>(buf, SW, act, lane, ROLE);
+      DCTS_STAMP(2);
+      split_butterflies<M, L>(buf, SW, act, lane, ROLE, trickle);
+      while (piece < FusedStage<M, L>::PIECES) FusedStage<M, L>::piece(nsrc, nstrip, nxt, lane, ROLE, piece++);
+      DCTS_STAMP(3);
       __syncthreads();
+      DCTS_STAMP(4);
       split_role_transform<M, L, ROLE>(buf + (act ? lane : 0), SW, parked[s]);
+      DCTS_STAMP(5);
       cur ^= 1;
     });
     // ---- pass 2: W axis, RPR role groups of parked rows per round ---------------------------
@@ -711,7 +761,9 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
     float e = 0.f;
     dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(ir)::value;
+      DCTS_STAMP(11);
       __syncthreads();  // previous readers of blk are done
+      DCTS_STAMP(6);
       if constexpr (Cfg::BALANCED) {
         dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
           constexpr int s = decltype(is)::value;
@@ -733,10 +785,14 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
           });
         });
       }
+      DCTS_STAMP(7);
       __syncthreads();
+      DCTS_STAMP(8);
       const bool act = lane < COLS;
       split_butterflies<M, L>(blk, RW, act, lane, ROLE);
+      DCTS_STAMP(9);
       __syncthreads();
+      DCTS_STAMP(10);
       float o[M];
       split_role_transform<M, L, ROLE>(blk + (act ? lane : 0), RW, o);
       float er = 0.f;
@@ -745,6 +801,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
         er = fmaf(o[k], o[k], er);
       });
       if (act) e += er;
+      DCTS_STAMP(12);
     });
     // ---- reduce: lanes -> wave -> workgroup, fixed order -------------------------------------
 #pragma unroll
@@ -758,7 +815,12 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       constexpr float sc = float(4.0 / (double(N) * double(N)));
       out[m] = t * sc;
     }
+    DCTS_STAMP(13);
   }
+#ifdef DCTS_FUSED_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_fused_stamps[ROLE][i], acc_[i]);
+#endif
 }
 
 template <int M, int L, int... R>
@@ -1404,6 +1466,16 @@ int dcts_running_mean_update_multi_f32(const dcts_update_desc* descs, int32_t co
   }
   return (int)hipGetLastError();
 }
+
+#ifdef DCTS_FUSED_STAMPS
+int dcts_debug_fused_stamps(unsigned long long* host_out /*[8][16]*/, int reset) {
+  if (reset) {
+    static unsigned long long zeros[8][16] = {};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), zeros, sizeof(zeros));
+  }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_stamps), 8 * 16 * sizeof(unsigned long long));
+}
+#endif
 
 int dcts_debug_stream_read_f32(const float* x, int64_t n, float* sink, void* stream) {
   if (!x || !sink) return DCTS_E_NULL;

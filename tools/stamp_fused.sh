@@ -1,0 +1,35 @@
+#!/bin/bash
+# Diagnostic: build libdctscore with s_memtime stamps in the fused kernel and print where a wave's
+# cycles go per phase. Run on the GPU box: tools/stamp_fused.sh [edge] [nmaps]
+set -e
+edge=${1:-224}; nmaps=${2:-4096}
+mkdir -p gpurun_out/stamps
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -DDCTS_FUSED_STAMPS \
+  -o gpurun_out/stamps/libdctscore_stamps.so dct_pruning_amd/csrc/dct_kernels.hip
+python3 - "$edge" "$nmaps" <<'PY'
+import ctypes, sys, torch
+edge, nmaps = int(sys.argv[1]), int(sys.argv[2])
+lib = ctypes.CDLL("gpurun_out/stamps/libdctscore_stamps.so")
+i64, i32, vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
+lib.dcts_energy_f32_ex.argtypes = [vp] + [i64] * 8 + [i32] * 3 + [vp, vp, ctypes.c_size_t, vp, i32]
+x = torch.relu(torch.randn(1, nmaps, edge, edge, device="cuda")); out = torch.empty(1, nmaps, device="cuda")
+def run():
+    rc = lib.dcts_energy_f32_ex(x.data_ptr(), 1, nmaps, edge, edge, *x.stride(), 0, nmaps, 0, out.data_ptr(), None, 0, None, 5)
+    assert rc == 0, rc
+run(); torch.cuda.synchronize()
+lib.dcts_debug_fused_stamps(None, 1)
+run(); torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 128)()
+lib.dcts_debug_fused_stamps(buf, 0)
+names = ["P1 wait vmcnt", "P1 barrier(top)", "P1 stage issue", "P1 butterflies", "P1 barrier(mid)", "P1 role transform",
+         "P2 barrier(pre-dump)", "P2 dump", "P2 barrier(post-dump)", "P2 butterflies", "P2 barrier(mid)", "loop glue",
+         "P2 role transform+energy", "reduce+store"]
+tot = [sum(buf[r * 16 + i] for r in range(8)) for i in range(16)]
+waves = 8 * min(nmaps, 256)
+all_ = sum(tot)
+print("fused %dx%d, %d maps: per-wave average cycles per map (s_memtime ticks = shader cycles / wave count)" % (edge, edge, nmaps))
+maps_per_wg = nmaps / min(nmaps, 256)
+for n, t in zip(names, tot):
+    print("  %-26s %10.0f  %5.1f%%" % (n, t / waves / maps_per_wg, 100.0 * t / all_))
+print("  %-26s %10.0f" % ("total", all_ / waves / maps_per_wg))
+PY
