@@ -243,3 +243,25 @@ def test_direct_kernel_workgroups_reuse_their_scratch_tile():
         check(x, got)
         again = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT)
         assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 2, 2), (1, 1, 7, 7), (1, 1, 56, 56), (1, 1, 224, 224), (2, 5000, 2, 2),
+                                   (1, 10, 7, 7), (3, 1, 9, 9), (1, 65, 14, 14), (1, 1, 512, 512), (1, 2, 320, 320),
+                                   (1, 3, 72, 72), (5, 7, 287, 287)])
+def test_edge_shapes(shape):
+    """Single maps, ragged last groups (maps not a multiple of the per-wave group), many tiny maps,
+    the largest supported edge, odd edges next to split sizes."""
+    x = synth(*shape, 900 + shape[2], dead=shape[1] > 7)
+    check(x, dpa.energy_nc(x.cuda()))
+    if shape[2] % 2 == 1:
+        check(x, dpa.energy_nc(x.cuda(), pad_front_if_odd=True), pad_front_if_odd=True)
+
+
+def test_empty_and_oversize_are_errors():
+    from dct_pruning_amd._lib import DctScoreError
+    with pytest.raises(DctScoreError):
+        dpa.energy_nc(torch.zeros(0, 4, 8, 8).cuda())
+    with pytest.raises(DctScoreError):
+        dpa.energy_nc(torch.zeros(1, 1, 513, 513).cuda())
+    with pytest.raises(DctScoreError):
+        dpa.energy_nc(torch.zeros(1, 1, 224, 224).cuda(), algo=dpa.ALGO_CODELET)
