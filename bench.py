@@ -141,14 +141,16 @@ def headline(lib, dev, stream_ptr, ws_fn):
     buffers rotated so the working set exceeds L2 + Infinity Cache."""
     out = {}
     for name, nmaps, h, nbuf in [("56x56", 16384, 56, 3), ("224x224", 4096, 224, 1), ("28x28", 65536, 28, 3),
-                                 ("14x14", 262144, 14, 3), ("7x7", 1048576, 7, 3), ("32x32", 65536, 32, 3)]:
+                                 ("14x14", 262144, 14, 3), ("7x7", 1048576, 7, 3), ("32x32", 65536, 32, 3),
+                                 ("288x288", 2048, 288, 1), ("320x320", 2048, 320, 1), ("144x144", 8192, 144, 1),
+                                 ("72x72", 32768, 72, 1)]:
         bufs = [synth(1, nmaps, h, h, 777 + i, dev) for i in range(nbuf)]
         ws = ws_fn(1, nmaps, h, h)
         units = [BoundUnit(lib, b, False, stream_ptr, ws) for b in bufs]
         for u in units:
             u.launch_energy()
         torch.cuda.synchronize(dev)
-        reps = 30 if h < 224 else 10
+        reps = 30 if h < 72 else 10
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for i in range(reps):
             ev[i][0].record()
