@@ -61,11 +61,17 @@ def main(argv=None):
         raise SystemExit("importance_generation.py needs a GPU: the score path has no CPU fallback")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dev = torch.device("cuda", local_rank)
+    # DCTS_REHEARSE=1: every rank on cuda:0 with a gloo group (to rehearse the sharded path on a
+    # one-GPU box); normal runs use one GPU per rank and RCCL
+    rehearse = os.environ.get("DCTS_REHEARSE") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=dev)
 
     torch.manual_seed(args.seed)
     net = nets.get_network(args.net)

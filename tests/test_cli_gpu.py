@@ -76,3 +76,26 @@ def test_cli_to_masks(tmp_path, name, bs, limit, extra):
                 diff = np.setxor1d(a, b)
                 cut = np.sort(r)[r.size - k]
                 assert np.all(np.abs(r[diff] - cut) <= 2e-4 * abs(cut)), stem
+
+
+def test_two_rank_cli_equals_single_rank(tmp_path):
+    """The layer-sharded path end to end (two ranks rehearsed on the one GPU, gloo group): rank 0
+    writes the same files as a single-rank run (1e-4: the forward pass re-runs)."""
+    common = ["--net", "resnet_56", "--dataset", "cifar10", "--synthetic", "--pretrain_dir", "", "--batch_size", "16",
+              "--limit", "2"]
+    (tmp_path / "one").mkdir()
+    (tmp_path / "two").mkdir()
+    run_cli(tmp_path / "one", *common)
+    env = dict(os.environ, PYTHONPATH=ROOT, DCTS_REHEARSE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733",
+                        os.path.join(ROOT, "importance_generation.py"), *common],
+                       cwd=tmp_path / "two", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout
+    d1 = tmp_path / "one" / "importance_score" / "resnet_56_limit2"
+    d2 = tmp_path / "two" / "importance_score" / "resnet_56_limit2"
+    assert sorted(os.listdir(d1)) == sorted(os.listdir(d2)) and len(os.listdir(d2)) == 55
+    for f in os.listdir(d1):
+        a, b = np.load(d1 / f), np.load(d2 / f)
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * float(a.max()), err_msg=f)
