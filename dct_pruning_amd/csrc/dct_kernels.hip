@@ -651,12 +651,12 @@ struct FusedCfg {
   static constexpr int S = 1 << L;
   static constexpr int SW = 64;
   static constexpr int STRIPS = (N + SW - 1) / SW;
-  static constexpr int RPR = (64 / M) >= 2 ? 2 : 1;          // role groups that fit the 64 lanes
+  static constexpr int RPR = (64 / M) >= 4 ? 4 : ((64 / M) >= 2 ? 2 : 1);  // role groups that fit the 64 lanes
   static constexpr int COLS = RPR * M;                       // pass-2 columns (lanes) per round
   // which parked rows go into a round: BALANCED = KPR coefficients of EVERY role (all waves dump,
   // equal work; every wave keeps its whole parked set live until the last round) or, where that
   // costs spills (M = 28: 112 parked + the codelet > 256 VGPRs), RPR whole roles per round
-  static constexpr bool BALANCED = (M == 32);
+  static constexpr bool BALANCED = (COLS % S == 0) && (M % (COLS / S > 0 ? COLS / S : 1) == 0) && (M % 4 == 0);
   static constexpr int KPR = COLS / S;
   static constexpr int ROUNDS = BALANCED ? M / KPR : S / RPR;
   static constexpr int RW = COLS | 1;                        // pass-2 image row stride (odd: conflict-free dump)
@@ -694,7 +694,7 @@ struct FusedStage {
 // Diagnostic build only (-DDCTS_FUSED_STAMPS, tools/stamp_fused.sh): s_memtime stamps at the phase
 // boundaries of the fused kernel, summed per wave into g_fused_stamps (never touches an output).
 #ifdef DCTS_FUSED_STAMPS
-__device__ unsigned long long g_fused_stamps[8][16];
+__device__ unsigned long long g_fused_stamps[16][16];
 #define DCTS_STAMP(slot)                                                          \
   do {                                                                            \
     unsigned long long t_;                                                        \
@@ -830,8 +830,19 @@ __device__ __forceinline__ void fused_dispatch(int role, const float* x, long lo
   ((role == R ? fused_body<M, L, R>(x, map_stride, nmaps, out, lds, partials, lane) : (void)0), ...);
 }
 
+// waves per SIMD the register file allows: STRIPS*M parked values + the codelet's working set
 template <int M, int L>
-__global__ __launch_bounds__((64 << L), 2) void k_split_fused(const float* __restrict__ x, long long map_stride,
+constexpr int fused_waves_per_simd() {
+  const int need = FusedCfg<M, L>::STRIPS * M + 72;
+  int w = 512 / ((need + 7) / 8 * 8);
+  const int per_wg = (1 << L) / 4 > 0 ? (1 << L) / 4 : 1;
+  if (w < per_wg) w = per_wg;
+  if (w > 8) w = 8;
+  return w;
+}
+
+template <int M, int L>
+__global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_split_fused(const float* __restrict__ x, long long map_stride,
                                                               long long nmaps, float* __restrict__ out) {
   using Cfg = FusedCfg<M, L>;
   __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF];
@@ -1226,8 +1237,11 @@ int launch_split(const MapGeom& g, float* out, void* workspace, hipStream_t st) 
   return (int)hipGetLastError();
 }
 
-// tiles whose intermediate fits the register file of one CU: single fused launch
-#define DCTS_FUSED_TABLE(X) X(224, 28, 3) X(256, 32, 3)
+// tiles whose intermediate fits the register file of one CU: single fused launch X(N, M, L).
+// (M, L) per edge is the fastest measured factorisation (e.g. 224: 28x8 roles 19 %, 14x16 roles 26 %;
+// 128: 16x8 38 %, 32x4 35 %, 8x16 22 %; 288 = 18x16 spills at 128 VGPRs and loses to two launches)
+#define DCTS_FUSED_TABLE(X) \
+  X(72, 9, 3) X(80, 10, 3) X(112, 14, 3) X(128, 16, 3) X(144, 18, 3) X(160, 10, 4) X(224, 14, 4) X(256, 16, 4)
 
 bool has_fused(long long N) {
 #define DCTS_CASE(N_, M_, L_) \
@@ -1240,7 +1254,15 @@ bool has_fused(long long N) {
 template <int M, int L>
 int launch_fused(const MapGeom& g, float* out, hipStream_t st) {
   const float* x0 = g.x + (long long)g.c_begin * g.strideC;
-  long long grid = g.nmaps < kNumCU ? g.nmaps : kNumCU;  // one workgroup per CU (LDS-limited)
+  // persistent grid: exactly the workgroups one residency holds (LDS- or register-limited)
+  static const int per_cu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split_fused<M, L>, 64 << L, 0) != hipSuccess || n < 1)
+      n = 1;
+    return n;
+  }();
+  const long long cap = (long long)kNumCU * per_cu;
+  const long long grid = g.nmaps < cap ? g.nmaps : cap;
   hipLaunchKernelGGL((k_split_fused<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, x0, g.strideC, g.nmaps,
                      out);
   return (int)hipGetLastError();
@@ -1468,12 +1490,12 @@ int dcts_running_mean_update_multi_f32(const dcts_update_desc* descs, int32_t co
 }
 
 #ifdef DCTS_FUSED_STAMPS
-int dcts_debug_fused_stamps(unsigned long long* host_out /*[8][16]*/, int reset) {
+int dcts_debug_fused_stamps(unsigned long long* host_out /*[16][16]*/, int reset) {
   if (reset) {
-    static unsigned long long zeros[8][16] = {};
+    static unsigned long long zeros[16][16] = {};
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), zeros, sizeof(zeros));
   }
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_stamps), 8 * 16 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fused_stamps), 16 * 16 * sizeof(unsigned long long));
 }
 #endif
 

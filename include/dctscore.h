@@ -60,7 +60,7 @@ enum {
   DCTS_ALGO_PREFETCH = 4, /* codelet kernel with direct-to-LDS prefetch of the next maps (dense,
                              even-edge square tiles; measured equal to ALGO_CODELET, opt-in)     */
   DCTS_ALGO_FUSED = 5     /* single-launch split kernel, intermediate tile parked in VGPRs
-                             (224x224, 256x256)                                                  */
+                             (edges 72, 80, 112, 128, 144, 160, 224, 256)                        */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */

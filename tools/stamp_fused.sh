@@ -19,13 +19,14 @@ def run():
 run(); torch.cuda.synchronize()
 lib.dcts_debug_fused_stamps(None, 1)
 run(); torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 128)()
+buf = (ctypes.c_ulonglong * 256)()
 lib.dcts_debug_fused_stamps(buf, 0)
 names = ["P1 wait vmcnt", "P1 barrier(top)", "P1 stage issue", "P1 butterflies", "P1 barrier(mid)", "P1 role transform",
          "P2 barrier(pre-dump)", "P2 dump", "P2 barrier(post-dump)", "P2 butterflies", "P2 barrier(mid)", "loop glue",
          "P2 role transform+energy", "reduce+store"]
-tot = [sum(buf[r * 16 + i] for r in range(8)) for i in range(16)]
-waves = 8 * min(nmaps, 256)
+nroles = sum(1 for r in range(16) if any(buf[r * 16 + i] for i in range(16)))
+tot = [sum(buf[r * 16 + i] for r in range(16)) for i in range(16)]
+waves = nroles * min(nmaps, 256)
 all_ = sum(tot)
 print("fused %dx%d, %d maps: per-wave average cycles per map (s_memtime ticks = shader cycles / wave count)" % (edge, edge, nmaps))
 maps_per_wg = nmaps / min(nmaps, 256)
