@@ -652,16 +652,20 @@ struct FusedCfg {
   static constexpr int SW = 64;
   static constexpr int STRIPS = (N + SW - 1) / SW;
   static constexpr int RPR = (64 / M) >= 4 ? 4 : ((64 / M) >= 2 ? 2 : 1);  // role groups that fit the 64 lanes
-  static constexpr int COLS = RPR * M;                       // pass-2 columns (lanes) per round
-  // which parked rows go into a round: BALANCED = KPR coefficients of EVERY role (all waves dump,
-  // equal work; every wave keeps its whole parked set live until the last round) or, where that
-  // costs spills (M = 28: 112 parked + the codelet > 256 VGPRs), RPR whole roles per round
-  static constexpr bool BALANCED = (COLS % S == 0) && (M % (COLS / S > 0 ? COLS / S : 1) == 0) && (M % 4 == 0);
-  static constexpr int KPR = COLS / S;
-  static constexpr int ROUNDS = BALANCED ? M / KPR : S / RPR;
-  static constexpr int RW = COLS | 1;                        // pass-2 image row stride (odd: conflict-free dump)
+  // which parked rows go into a pass-2 round:
+  //  BALANCED: KPR = 64/S coefficients of EVERY role (all waves dump, equal work; M is padded up to
+  //            ROUNDS*KPR with zero columns) - used where the padding wastes <= 1/6 of the columns;
+  //  otherwise RPR whole roles per round (only their waves dump).
+  static constexpr int KPR_B = 64 / S;
+  static constexpr int ROUNDS_B = (M + KPR_B - 1) / KPR_B;
+  static constexpr bool BALANCED = (S <= 64) && (6 * (ROUNDS_B * KPR_B - M) <= ROUNDS_B * KPR_B) &&
+                                   !(M == 14 && L == 4) && M != 28;  // those two spill when every wave keeps its parked set live
+  static constexpr int KPR = KPR_B;
+  static constexpr int COLS = BALANCED ? S * KPR_B : RPR * M;  // pass-2 columns (lanes) per round
+  static constexpr int ROUNDS = BALANCED ? ROUNDS_B : S / RPR;
+  static constexpr int RW = COLS | 1;                          // pass-2 image row stride (odd: conflict-free dump)
   static constexpr int BUF = (N * SW > N * RW ? N * SW : N * RW);  // floats per LDS buffer
-  static_assert(N % 4 == 0 && S % RPR == 0 && (!BALANCED || (COLS % S == 0 && M % KPR == 0)), "shape");
+  static_assert(N % 4 == 0 && S % RPR == 0, "shape");
 };
 
 // one direct-to-LDS instruction (64 lanes x 16 B) of a strip's staging: piece `it` of PIECES.
@@ -771,7 +775,11 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
           const int off = (line < N ? line : 0) * RW + ROLE * KPR;
           dcts::static_for<KPR>([&](auto ik) DCTS_LAMBDA_INLINE {
             constexpr int k = decltype(ik)::value;
-            if (line < N) blk[off + k] = parked[s][r * KPR + k];
+            if constexpr (r * KPR + k < M) {
+              if (line < N) blk[off + k] = parked[s][r * KPR + k];
+            } else {
+              if (line < N) blk[off + k] = 0.f;  // padding column: contributes exactly zero energy
+            }
           });
         });
       } else if constexpr (ROLE / RPR == r) {
