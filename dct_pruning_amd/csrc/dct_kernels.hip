@@ -433,7 +433,7 @@ struct RolePlan {
 template <int M, int L>
 struct RotTable {
   static constexpr int NR = (RolePlan<L>::NOPS > 0 ? RolePlan<L>::NOPS : 1);
-  float c[NR][M] = {}, s[NR][M] = {}, sg[NR][M] = {};
+  float c[NR][M] = {}, s[NR][M] = {};
   constexpr RotTable() {
     constexpr RolePlan<L> plan{};
     for (int r = 0; r < plan.nrot; ++r)
@@ -442,8 +442,13 @@ struct RotTable {
         const int n = plan.rot_c[r] * M;
         c[r][p] = float(dcts::cospi_frac(2 * j + 1, 4 * n));
         s[r][p] = float(dcts::sinpi_frac(2 * j + 1, 4 * n));
-        sg[r][p] = (j % 2 == 0) ? 1.f : -1.f;
       }
+  }
+  // (-1)^j = sign0(r) * (-1)^p: the sign of the second rotation output needs no table
+  static constexpr float sign0(int r) {
+    constexpr RolePlan<L> plan{};
+    const int j0 = plan.rot_seg[r] * M + (plan.rot_asc[r] ? 0 : M - 1);
+    return (j0 % 2 == 0) ? 1.f : -1.f;
   }
 };
 template <int M, int L>
@@ -475,6 +480,7 @@ __device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lan
   const RotTable<M, L>& tab = kRotTable<M, L>;
   lds_ptr colp = base + (lane_ok ? lane : 0);
   for (int p = wave; p < M; p += S) {
+    const float sp = (p & 1) ? -1.f : 1.f;  // (-1)^p
     float y[S];
     dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
       constexpr int s = decltype(i)::value;
@@ -489,9 +495,10 @@ __device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lan
         y[a] = ya + yb;
         y[bb] = ya - yb;
       } else {
-        const float c = tab.c[r][p], sn = tab.s[r][p], sg = tab.sg[r][p];
+        const float c = tab.c[r][p], sn = tab.s[r][p];
+        constexpr float k0 = RotTable<M, L>::sign0(r);
         y[a] = ya * c + yb * sn;
-        y[bb] = sg * (yb * c - ya * sn);
+        y[bb] = (k0 * sp) * (yb * c - ya * sn);
       }
     });
     if (lane_ok) {
