@@ -163,6 +163,10 @@ def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host
     """Counterpart of utils/common.py:367-977. `args` needs .net, .limit (and whatever
     load_data reads when train_loader is None)."""
     global _acc
+    if not hasattr(args, "limit"):
+        # utils/load_models.py:819 calls imp_score from prune_*.py whose parsers define no --limit
+        # (AttributeError in the reference as shipped); fall back to importance_generation.py's default
+        args.limit = 5
     out_dir = "importance_score/" + args.net + "_limit" + str(args.limit)
     world, rank = 1, 0
     if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
