@@ -22,7 +22,8 @@ for _ in range(3):
     y.copy_(x)
 del y
 torch.cuda.synchronize()
-for edge, nmaps in [(56, 65536), (28, 262144), (14, 1048576), (7, 4194304), (32, 196608), (224, 4096)]:
+for edge, nmaps in [(56, 65536), (28, 262144), (14, 1048576), (7, 4194304), (32, 196608), (224, 4096), (128, 12288),
+                    (288, 2048)]:
     t = torch.relu(torch.randn(1, nmaps, edge, edge, device=dev))
     for _ in range(3):
         dpa.energy_nc(t)

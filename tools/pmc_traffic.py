@@ -24,6 +24,7 @@ def load(d, counter):
 
 
 PROBE_SHAPES = {56: 65536, 28: 262144, 14: 1048576, 7: 4194304, 32: 196608}  # tools/pmc_probe.py
+PROBE_FUSED = {(14, 4): (224, 4096), (16, 3): (128, 12288)}  # k_split_fused<M, L> -> (edge, maps)
 
 
 def main(dfetch, dwrite):
@@ -48,6 +49,9 @@ def main(dfetch, dwrite):
         alg = None
         for edge, nmaps in PROBE_SHAPES.items():
             if key.startswith("k_energy_codelet_%d_%d_" % (edge, edge)):
+                alg = nmaps * (4 * edge * edge + 4)
+        for (mm, ll), (edge, nmaps) in PROBE_FUSED.items():
+            if key == "k_split_fused_%d_%d" % (mm, ll):
                 alg = nmaps * (4 * edge * edge + 4)
         out[key] = {"launches": len(vals), "alg_bytes_per_launch": alg,
                     "hbm_over_alg": (((raw * factor if factor else raw) + (wb or 0.0)) / alg) if alg else None,
