@@ -4,9 +4,10 @@
 Workload (BASELINE.json configs[3], the one the metric's 1/2/4/8-GPU figures are quoted on):
 the 49 hooked tensors of imp_score for resnet_50 (utils/common.py:557-607; shapes in
 dct_pruning_amd/schedules.py) at batch 256, fp32, synthetic, resident in HBM
-before the clock starts. One STEP = one batch pass of the hot path: for every hooked tensor
-one DCT+energy launch ([N,C,H,W] -> [N,C]), then one batch-sum/running-mean launch covering all
-hooked tensors (utils/common.py:265-277). After the K timed steps (= `--limit K` batches) multi-GPU runs do
+before the clock starts. One STEP = one batch pass of the hot path: one DCT+energy launch per tile
+shape covering every hooked tensor of that shape (dcts_energy_multi_f32: [N,C,H,W] -> [N,C] each;
+`--per-tensor` launches them one by one as the per-hook harness does), then one batch-sum /
+running-mean launch covering all hooked tensors (utils/common.py:265-277). After the K timed steps (= `--limit K` batches) multi-GPU runs do
 the path's single exchange: one RCCL all-gather of the flat score buffer; it is inside the
 timed region.
 
@@ -42,6 +43,8 @@ def parse():
     ap.add_argument("--net", default="resnet_50")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-headline", action="store_true")
+    ap.add_argument("--per-tensor", action="store_true",
+                    help="one energy launch per hooked tensor (default: one dcts_energy_multi_f32 launch per tile shape)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -237,19 +240,49 @@ def main():
         descs[k].energy_nc, descs[k].feature_result = b.energy.data_ptr(), b.fr.data_ptr()
         descs[k].N, descs[k].C_count = b.n, b.fr.numel()
 
+    # multi-launch plan: all units of one tile shape go into one dcts_energy_multi_f32 call
+    by_shape = {}
+    for _, b in bound:
+        by_shape.setdefault(b.h, []).append(b)
+    multi = []
+    for h, bs in sorted(by_shape.items(), key=lambda kv: -kv[0]):
+        arr = (_lib.TensorItem * len(bs))()
+        for i, b in enumerate(bs):
+            arr[i].x, arr[i].out_nc = b.x.data_ptr(), b.energy.data_ptr()
+            arr[i].N, arr[i].C_total = b.x.shape[0], b.x.shape[1]
+            arr[i].strideN, arr[i].strideC = b.x.stride(0), b.x.stride(1)
+            arr[i].c_begin, arr[i].c_count = 0, b.x.shape[1]
+        ws = ws_fn(max(b.x.shape[0] for b in bs), max(b.x.shape[1] for b in bs), h, h)
+        multi.append((h, arr, len(bs), ws))
+
     def step(events=None):
-        in_dom = False
-        for _, b in bound:
-            if events is not None and (b.h == dom_edge) != in_dom:
+        if args.per_tensor:
+            in_dom = False
+            for _, b in bound:
+                if events is not None and (b.h == dom_edge) != in_dom:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    events.append(ev)
+                    in_dom = not in_dom
+                b.launch_energy()
+            if events is not None and in_dom:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 events.append(ev)
-                in_dom = not in_dom
-            b.launch_energy()
-        if events is not None and in_dom:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            events.append(ev)
+        else:
+            for h, arr, n, ws in multi:
+                timed = events is not None and h == dom_edge
+                if timed:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    events.append(ev)
+                rc = lib.dcts_energy_multi_f32(arr, n, h, h, 0, ws.data_ptr(), ws.numel(), stream_ptr)
+                if rc:
+                    raise RuntimeError("dcts_energy_multi_f32 -> %d" % rc)
+                if timed:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    events.append(ev)
         for k, (_, b) in enumerate(bound):
             descs[k].total_before = b.total
             b.total += b.n
@@ -303,7 +336,7 @@ def main():
     # events come in (start, stop) pairs around each contiguous group of dominant-kernel launches
     dom_ms = sum(events[i].elapsed_time(events[i + 1]) for i in range(0, len(events), 2))
     dom_bytes = sum(b.bytes for b in dom) * args.steps
-    n_launch = max(len(dom) * args.steps, 1)
+    n_launch = max((len(dom) if args.per_tensor else -(-len(dom) // 32)) * args.steps, 1)
 
     if rank == 0:
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -314,6 +347,7 @@ def main():
             # WRITE_SIZE in separate runs, read side corrected x2 by the dword-per-lane calibration
             # kernel), scaled from the probe's launch size to this run's algorithmic bytes per launch
             try:
+                # the multi-tensor kernel runs the same per-group code as k_energy_codelet: same traffic
                 rec = json.load(open(tpath)).get("k_energy_codelet_%d_%d_0_false" % (dom_edge, dom_edge), {})
                 if rec.get("hbm_over_alg"):
                     traffic = rec["hbm_over_alg"] * dom_bytes / n_launch
@@ -327,9 +361,12 @@ def main():
             "config": {"workload": "%s hooked feature maps (49 tensors, %d maps/sample: 56x56 x1344, 28x28 x3200, "
                                    "14x14 x9472, 7x7 x8704), batch %d, limit=steps" % (args.net, sum(chans), N),
                        "global_batch": N, "sharding": "layer-sharded (LPT on bytes), 1 all-gather" if world > 1 else "none",
+                       "launch_mode": "per-tensor" if args.per_tensor else "one launch per tile shape",
                        "units_rank0": len(bound), "load_imbalance": (max(load) / (sum(load) / world)) if world > 1 else 1.0},
             "GB_s_whole_step": total_cost * args.steps / dt / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "k_energy_codelet<%d,%d>" % (dom_edge, dom_edge),
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_energy_codelet<%d,%d>" if args.per_tensor or dom_edge > 64 else
+                                    "k_energy_codelet_multi<%d,%d>") % (dom_edge, dom_edge),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": n_launch, "avg_launch_us": dom_ms / n_launch * 1e3,

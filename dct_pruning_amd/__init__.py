@@ -15,8 +15,9 @@ from .ops import (  # noqa: F401
     ALGO_SPLIT,
     batch_sum,
     dct2d,
+    energy_multi,
     energy_nc,
     has_codelet,
 )
 
-__all__ = ["energy_nc", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED"]
+__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED"]

@@ -32,6 +32,7 @@ SIGNATURES = {
                                          _i32, _i32, _i32, _vp, _vp, _sz, _vp, _i32]),
     "dcts_batch_sum_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "dcts_running_mean_update_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.c_float, _vp]),
+    "dcts_energy_multi_f32": (ctypes.c_int, [_vp, _i32, _i64, _i64, _i32, _vp, _sz, _vp]),
     "dcts_running_mean_update_multi_f32": (ctypes.c_int, [_vp, _i32, _vp]),
     "dcts_debug_stream_read_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
 }
@@ -41,6 +42,12 @@ class UpdateDesc(ctypes.Structure):
     """struct dcts_update_desc (include/dctscore.h)."""
     _fields_ = [("energy_nc", _vp), ("feature_result", _vp), ("N", _i64), ("C_count", _i64),
                 ("total_before", ctypes.c_float), ("reserved", _i32)]
+
+
+class TensorItem(ctypes.Structure):
+    """struct dcts_tensor_item (include/dctscore.h)."""
+    _fields_ = [("x", _vp), ("out_nc", _vp), ("N", _i64), ("C_total", _i64), ("strideN", _i64), ("strideC", _i64),
+                ("c_begin", _i32), ("c_count", _i32)]
 
 
 class DctScoreError(RuntimeError):

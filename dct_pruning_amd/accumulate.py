@@ -66,8 +66,9 @@ class DeviceAccumulator:
 class DeviceBatchAccumulator:
     def __init__(self, device):
         self.device = torch.device(device)
-        self.state = {}    # key -> [feature_result tensor, total]
-        self.pending = {}  # key -> energy tensor of the current batch
+        self.state = {}      # key -> [feature_result tensor, total]
+        self.pending = {}    # key -> energy tensor of the current batch
+        self.pending_x = {}  # key -> (hooked tensor, c_begin, c_count, pad) awaiting deferred scoring
 
     def add(self, key, energy_nc):
         if key in self.pending:  # the same hook fired again: a new batch has started
@@ -77,7 +78,31 @@ class DeviceBatchAccumulator:
             self.state[key] = [torch.zeros(e.shape[1], dtype=torch.float32, device=self.device), 0.0]
         self.pending[key] = e
 
+    def add_tensor(self, key, x, c_begin, c_count, pad):
+        """Deferred scoring: keep a reference to the hooked tensor; its energy is computed at flush time
+        together with every other pending tensor of the same tile shape (ops.energy_multi). The caller
+        guarantees nothing overwrites the tensor before the flush (true for the reference's nets: hooked
+        tensors are ReLU / pool / concat outputs that later layers only read)."""
+        if key in self.pending or key in self.pending_x:
+            self.flush()
+        self.pending_x[key] = (x, c_begin, c_count, pad)
+
+    def _score_pending_tensors(self):
+        from . import ops
+        groups = {}
+        for key, (x, cb, cc, pad) in self.pending_x.items():
+            groups.setdefault((x.shape[2], x.shape[3], bool(pad)), []).append(key)
+        for (h, w, pad), keys in groups.items():
+            outs = ops.energy_multi([self.pending_x[k][:3] for k in keys], pad_front_if_odd=pad)
+            for k, e in zip(keys, outs):
+                if k not in self.state:
+                    self.state[k] = [torch.zeros(e.shape[1], dtype=torch.float32, device=self.device), 0.0]
+                self.pending[k] = e
+        self.pending_x.clear()
+
     def flush(self):
+        if self.pending_x:
+            self._score_pending_tensors()
         if not self.pending:
             return
         keys = list(self.pending)

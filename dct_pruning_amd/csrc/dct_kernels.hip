@@ -69,12 +69,96 @@ struct CodeletCfg {
   static constexpr int WAVES = (WAVE_LDS * 4 * 4 <= 49152) ? 4 : ((WAVE_LDS * 4 * 2 <= 49152) ? 2 : 1);
 };
 
+// one group of G maps: both passes, the LDS transpose and the reduction (see the header comment)
+template <int HP, int WP, int PAD, bool STORE_COEFF>
+__device__ __forceinline__ void codelet_group(const MapGeom& g, float* __restrict__ out, long long grp,
+                                              float* my, int g1, int c, int g2, int k, bool act1, bool act2) {
+  using Cfg = CodeletCfg<HP, WP>;
+  constexpr int G = Cfg::G, S = Cfg::S, MAP_LDS = Cfg::MAP_LDS;
+  constexpr int W = WP - PAD;  // data row length == row stride (dense rows)
+  // ---- pass 1: column DCT-II of length HP, lane = column -------------------------
+  const long long m1 = grp * G + g1;
+  float xr[HP];
+  const bool ld = act1 && m1 < g.nmaps && c >= PAD;
+  if (ld) {
+    const float* p = map_base(g, m1) + (c - PAD);
+    dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int r = decltype(i)::value;
+      if constexpr (r < PAD)
+        xr[r] = 0.f;
+      else
+        xr[r] = p[(r - PAD) * W];
+    });
+  } else {
+    dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE { xr[decltype(i)::value] = 0.f; });
+  }
+  float y[HP];
+  dcts::Dct2<HP>::run(xr, y);
+  y[0] *= dcts::kInvSqrt2;
+  if (act1) {
+    float* dst = my + g1 * MAP_LDS + c;
+    dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int kk = decltype(i)::value;
+      dst[kk * S] = y[kk];
+    });
+  }
+  // the wave's own LDS traffic is in order; only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- pass 2: row DCT-II of length WP, lane = row --------------------------------
+  float z[WP], w[WP];
+  {
+    const float* src = my + (act2 ? g2 : 0) * MAP_LDS + (act2 ? k : 0) * S;
+    dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int cc = decltype(i)::value;
+      z[cc] = src[cc];
+    });
+  }
+  dcts::Dct2<WP>::run(z, w);
+  w[0] *= dcts::kInvSqrt2;
+  const long long m2 = grp * G + g2;
+  if constexpr (STORE_COEFF) {
+    // debug/parity path: out is [nmaps][HP][WP] orthonormal coefficients
+    if (act2 && m2 < g.nmaps) {
+      constexpr float sc = float(2.0 / dcts::cx_sqrt(double(HP) * double(WP)));
+      float* o = out + (m2 * HP + k) * WP;
+      dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int l = decltype(i)::value;
+        o[l] = w[l] * sc;
+      });
+    }
+  } else {
+    float e = 0.f;
+    dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int l = decltype(i)::value;
+      e = fmaf(w[l], w[l], e);
+    });
+    if (!act2) e = 0.f;
+    // segmented reduction over the HP lanes of each map (lane k == 0 ends with the sum)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      if (off < HP) {
+        const float t = __shfl_down(e, off, 64);
+        if (k + off < HP) e += t;
+      }
+    }
+    if (act2 && k == 0 && m2 < g.nmaps) {
+      constexpr float sc = float(4.0 / (double(HP) * double(WP)));
+      out[m2] = e * sc;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int HP, int WP, int PAD, bool STORE_COEFF>
 __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_codelet(
     MapGeom g, float* __restrict__ out) {
   using Cfg = CodeletCfg<HP, WP>;
-  constexpr int G = Cfg::G, S = Cfg::S, MAP_LDS = Cfg::MAP_LDS, WAVES = Cfg::WAVES;
-  constexpr int W = WP - PAD;  // data row length == row stride (dense rows)
+  constexpr int G = Cfg::G, WAVES = Cfg::WAVES;
   __shared__ float slab[WAVES][Cfg::WAVE_LDS];
 
   const int lane = threadIdx.x & 63;
@@ -90,83 +174,47 @@ __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_cod
   const long long wave_gid = (long long)blockIdx.x * WAVES + wave;
   const long long nwaves = (long long)gridDim.x * WAVES;
 
-  for (long long grp = wave_gid; grp < ngroups; grp += nwaves) {
-    // ---- pass 1: column DCT-II of length HP, lane = column -------------------------
-    const long long m1 = grp * G + g1;
-    float xr[HP];
-    const bool ld = act1 && m1 < g.nmaps && c >= PAD;
-    if (ld) {
-      const float* p = map_base(g, m1) + (c - PAD);
-      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
-        constexpr int r = decltype(i)::value;
-        if constexpr (r < PAD)
-          xr[r] = 0.f;
-        else
-          xr[r] = p[(r - PAD) * W];
-      });
-    } else {
-      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE { xr[decltype(i)::value] = 0.f; });
-    }
-    float y[HP];
-    dcts::Dct2<HP>::run(xr, y);
-    y[0] *= dcts::kInvSqrt2;
-    if (act1) {
-      float* dst = my + g1 * MAP_LDS + c;
-      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
-        constexpr int kk = decltype(i)::value;
-        dst[kk * S] = y[kk];
-      });
-    }
-    // the wave's own LDS traffic is in order; only the compiler must not reorder
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (long long grp = wave_gid; grp < ngroups; grp += nwaves)
+    codelet_group<HP, WP, PAD, STORE_COEFF>(g, out, grp, my, g1, c, g2, k, act1, act2);
+}
 
-    // ---- pass 2: row DCT-II of length WP, lane = row --------------------------------
-    float z[WP], w[WP];
-    {
-      const float* src = my + (act2 ? g2 : 0) * MAP_LDS + (act2 ? k : 0) * S;
-      dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
-        constexpr int cc = decltype(i)::value;
-        z[cc] = src[cc];
-      });
-    }
-    dcts::Dct2<WP>::run(z, w);
-    w[0] *= dcts::kInvSqrt2;
-    const long long m2 = grp * G + g2;
-    if constexpr (STORE_COEFF) {
-      // debug/parity path: out is [nmaps][HP][WP] orthonormal coefficients
-      if (act2 && m2 < g.nmaps) {
-        constexpr float sc = float(2.0 / dcts::cx_sqrt(double(HP) * double(WP)));
-        float* o = out + (m2 * HP + k) * WP;
-        dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
-          constexpr int l = decltype(i)::value;
-          o[l] = w[l] * sc;
-        });
-      }
-    } else {
-      float e = 0.f;
-      dcts::static_for<WP>([&](auto i) DCTS_LAMBDA_INLINE {
-        constexpr int l = decltype(i)::value;
-        e = fmaf(w[l], w[l], e);
-      });
-      if (!act2) e = 0.f;
-      // segmented reduction over the HP lanes of each map (lane k == 0 ends with the sum)
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) {
-        if (off < HP) {
-          const float t = __shfl_down(e, off, 64);
-          if (k + off < HP) e += t;
-        }
-      }
-      if (act2 && k == 0 && m2 < g.nmaps) {
-        constexpr float sc = float(4.0 / (double(HP) * double(WP)));
-        out[m2] = e * sc;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// Several hooked tensors of the same tile shape in ONE launch (single-sweep harness, bench): the
+// groups of all tensors form one index space; a wave walks it with a grid stride and tracks which
+// tensor its current group belongs to. CIFAR-sized layers are 5-20 us kernels when launched one
+// by one - the launch ramp and tail cost more than the work.
+constexpr int kMultiItems = 32;
+struct MultiItem {
+  MapGeom g;
+  float* out;
+  long long group_begin;  // first global group index of this tensor
+};
+struct MultiGeom {
+  MultiItem it[kMultiItems];
+  long long total_groups;
+  int count;
+};
+
+template <int HP, int WP, int PAD>
+__global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_codelet_multi(MultiGeom mg) {
+  using Cfg = CodeletCfg<HP, WP>;
+  constexpr int G = Cfg::G, WAVES = Cfg::WAVES;
+  __shared__ float slab[WAVES][Cfg::WAVE_LDS];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* my = slab[wave];
+  const int g1 = lane / WP, c = lane - g1 * WP;
+  const int g2 = lane / HP, k = lane - g2 * HP;
+  const bool act1 = g1 < G, act2 = g2 < G;
+
+  const long long wave_gid = (long long)blockIdx.x * WAVES + wave;
+  const long long nwaves = (long long)gridDim.x * WAVES;
+  int t = 0;
+  for (long long grp = wave_gid; grp < mg.total_groups; grp += nwaves) {
+    while (t + 1 < mg.count && grp >= mg.it[t + 1].group_begin) ++t;  // wave-uniform, monotone
+    t = __builtin_amdgcn_readfirstlane(t);
+    const MultiItem& item = mg.it[t];
+    codelet_group<HP, WP, PAD, false>(item.g, item.out, grp - item.group_begin, my, g1, c, g2, k, act1, act2);
   }
 }
 
@@ -1307,6 +1355,44 @@ int dispatch_split(int N, const MapGeom& g, float* out, void* workspace, hipStre
 #undef DCTS_CASE
 }
 
+template <int HP, int WP, int PAD>
+int launch_codelet_multi(const MultiGeom& mg, hipStream_t st) {
+  using Cfg = CodeletCfg<HP, WP>;
+  long long blocks = (mg.total_groups + Cfg::WAVES - 1) / Cfg::WAVES;
+  const long long cap = (long long)kNumCU * 32 / Cfg::WAVES;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((k_energy_codelet_multi<HP, WP, PAD>), dim3((unsigned)blocks), dim3(64 * Cfg::WAVES), 0, st,
+                     mg);
+  return (int)hipGetLastError();
+}
+
+int codelet_group_size(int HP) {
+#define DCTS_CASE(N) \
+  if (HP == N) return CodeletCfg<N, N>::G;
+  DCTS_CODELET_SIZES(DCTS_CASE)
+#undef DCTS_CASE
+  return 0;
+}
+
+int dispatch_codelet_multi(int HP, int pad, const MultiGeom& mg, hipStream_t st) {
+#define DCTS_CASE(N)                                        \
+  case N:                                                   \
+    if (pad) {                                              \
+      if constexpr ((N % 2) == 0 && N >= 2)                 \
+        return launch_codelet_multi<N, N, 1>(mg, st);       \
+      else                                                  \
+        return DCTS_E_UNSUPPORTED;                          \
+    }                                                       \
+    return launch_codelet_multi<N, N, 0>(mg, st);
+  switch (HP) {
+    DCTS_CODELET_SIZES(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+
 bool has_codelet(long long HP, long long WP) {
   if (HP != WP) return false;
 #define DCTS_CASE(N) \
@@ -1481,6 +1567,61 @@ int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_co
   hipLaunchKernelGGL(k_running_mean, dim3((unsigned)((C_count + kSumCh - 1) / kSumCh)), dim3(kSumCh * kSumSl), 0, st,
                      energy_nc, (long long)N, (long long)C_count, feature_result, total_before);
   return (int)hipGetLastError();
+}
+
+int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t H, int64_t W,
+                          int32_t pad_front_if_odd, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!items) return DCTS_E_NULL;
+  if (count <= 0 || H <= 0 || W <= 0) return DCTS_E_SHAPE;
+  const int pad = (pad_front_if_odd && (H % 2 != 0)) ? 1 : 0;
+  const int64_t HP = H + pad, WP = W + pad;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int32_t i = 0; i < count; ++i) {
+    const dcts_tensor_item& t = items[i];
+    if (!t.x || !t.out_nc) return DCTS_E_NULL;
+    if (t.N <= 0 || t.C_total <= 0) return DCTS_E_SHAPE;
+    if (t.c_count <= 0 || t.c_begin < 0 || (int64_t)t.c_begin + t.c_count > t.C_total) return DCTS_E_CHANNELS;
+    if ((reinterpret_cast<uintptr_t>(t.x) & 3) || (reinterpret_cast<uintptr_t>(t.out_nc) & 3)) return DCTS_E_ALIGN;
+  }
+  if (has_codelet(HP, WP)) {
+    const int G = codelet_group_size((int)HP);
+    for (int32_t i0 = 0; i0 < count; i0 += kMultiItems) {
+      const int n = (count - i0) < kMultiItems ? (count - i0) : kMultiItems;
+      MultiGeom mg;
+      long long groups = 0;
+      for (int i = 0; i < n; ++i) {
+        const dcts_tensor_item& t = items[i0 + i];
+        MapGeom& g = mg.it[i].g;
+        g.x = t.x;
+        g.nmaps = t.N * (int64_t)t.c_count;
+        g.strideN = t.strideN;
+        g.strideC = t.strideC;
+        g.strideH = W;
+        g.c_count = t.c_count;
+        g.c_begin = t.c_begin;
+        g.H = (int)H;
+        g.W = (int)W;
+        g.contiguous = (t.N == 1 || t.strideN == (int64_t)t.c_count * t.strideC) ? 1 : 0;
+        mg.it[i].out = t.out_nc;
+        mg.it[i].group_begin = groups;
+        groups += (g.nmaps + G - 1) / G;
+      }
+      for (int i = n; i < kMultiItems; ++i) mg.it[i] = mg.it[0];
+      mg.total_groups = groups;
+      mg.count = n;
+      const int rc = dispatch_codelet_multi((int)HP, pad, mg, st);
+      if (rc) return rc;
+    }
+    return DCTS_OK;
+  }
+  // shapes without a codelet: one call per tensor (fused / split / direct), same stream
+  for (int32_t i = 0; i < count; ++i) {
+    const dcts_tensor_item& t = items[i];
+    const int rc = run<false>(t.x, t.N, t.C_total, H, W, t.strideN, t.strideC, W, 1, t.c_begin, t.c_count,
+                              pad_front_if_odd, t.out_nc, workspace, workspace_bytes, stream, DCTS_ALGO_AUTO);
+    if (rc) return rc;
+  }
+  return DCTS_OK;
 }
 
 int dcts_running_mean_update_multi_f32(const dcts_update_desc* descs, int32_t count, void* stream) {

@@ -17,6 +17,9 @@ Additions (opt-in, results identical on fixed batches):
   single_sweep=True   all hook points registered at once, one sweep instead of 12..118
                       (SURVEY.md §8 f1);
   accumulate="device" running mean kept on the GPU (dcts_running_mean_update_f32);
+  deferred=True       single sweep where the hooks only keep references; at the end of each batch
+                      all tensors of one tile shape are scored in ONE launch
+                      (dcts_energy_multi_f32) and all running means in one more;
   world_size > 1      hook points LPT-sharded over ranks, one all-gather at the end,
                       rank 0 writes the files.
 """
@@ -140,11 +143,19 @@ class _PointHook:
     """A hook with its own accumulator (single-sweep / device modes). With `batch` set, the
     device-side update is deferred and fused across hook points (DeviceBatchAccumulator)."""
 
-    def __init__(self, kind, accumulate, device, batch=None, key=None):
+    def __init__(self, kind, accumulate, device, batch=None, key=None, deferred=False):
         self.kind, self.accumulate, self.device, self.acc = kind, accumulate, device, None
-        self.batch, self.key = batch, key
+        self.batch, self.key, self.deferred = batch, key, deferred
 
     def __call__(self, module, inputs, output):
+        if self.deferred and self.batch is not None:
+            x = _scored_tensor(self.kind, inputs, output)
+            b = x.shape[1]
+            if self.kind == "last12":
+                self.batch.add_tensor(self.key, x, b - 12, 12, True)
+            else:
+                self.batch.add_tensor(self.key, x, 0, b, self.kind == "input")
+            return
         e = _hook_energy(self.kind, _scored_tensor(self.kind, inputs, output))
         if self.batch is not None:
             self.batch.add(self.key, e)
@@ -159,7 +170,7 @@ class _PointHook:
         return np.ascontiguousarray(self.acc.scores(), dtype=np.float32)
 
 
-def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host", group=None):
+def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host", group=None, deferred=False):
     """Counterpart of utils/common.py:367-977. `args` needs .net, .limit (and whatever
     load_data reads when train_loader is None)."""
     global _acc
@@ -200,11 +211,13 @@ def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host
     mine = [i for i in range(len(pts)) if owner[i] == rank]
     results = {}
 
+    if deferred:
+        single_sweep, accumulate = True, "device"
     if single_sweep:
         hooks, handles = {}, []
         batch = DeviceBatchAccumulator(dev) if (accumulate == "device" and dev.type == "cuda") else None
         for i in mine:
-            hooks[i] = _PointHook(pts[i].kind, accumulate, dev, batch=batch, key=i)
+            hooks[i] = _PointHook(pts[i].kind, accumulate, dev, batch=batch, key=i, deferred=deferred)
             handles.append(_resolve(net, pts[i].module).register_forward_hook(hooks[i]))
         sweep(net, train_loader, args.limit)
         for h in handles:

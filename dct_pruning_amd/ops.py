@@ -98,3 +98,39 @@ def batch_sum(energy):
         _lib.check(_lib.load().dcts_batch_sum_f32(energy.data_ptr(), energy.shape[0], energy.shape[1],
                                                   out.data_ptr(), stream))
     return out
+
+
+def energy_multi(items, pad_front_if_odd=False):
+    """energy_nc for several tensors of the SAME (H, W) in one launch.
+
+    items: list of (x, c_begin, c_count) with x [N, C, H, W] fp32 CUDA (c_count None = to the end).
+    Returns the list of [N, c_count] outputs. Tensors must stay alive until the stream has run."""
+    lib = _lib.load()
+    if not items:
+        return []
+    H, W = items[0][0].shape[2], items[0][0].shape[3]
+    dev = items[0][0].device
+    arr = (_lib.TensorItem * len(items))()
+    outs, keep = [], []
+    need = 0
+    for i, (x, c_begin, c_count) in enumerate(items):
+        _check_input(x)
+        if x.shape[2] != H or x.shape[3] != W or x.device != dev:
+            raise ValueError("energy_multi needs tensors of one tile shape on one device")
+        if x.stride(3) != 1 or x.stride(2) != W:
+            x = x.contiguous()
+        c_begin, c_count = _slice(x, c_begin, c_count)
+        out = torch.empty((x.shape[0], c_count), dtype=torch.float32, device=dev)
+        keep.append(x)
+        outs.append(out)
+        arr[i].x, arr[i].out_nc = x.data_ptr(), out.data_ptr()
+        arr[i].N, arr[i].C_total = x.shape[0], x.shape[1]
+        arr[i].strideN, arr[i].strideC = x.stride(0), x.stride(1)
+        arr[i].c_begin, arr[i].c_count = c_begin, c_count
+        need = max(need, lib.dcts_workspace_bytes(x.shape[0], c_count, H, W))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = _workspace(dev, stream, need)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dcts_energy_multi_f32(arr, len(items), H, W, 1 if pad_front_if_odd else 0,
+                                             ws.data_ptr(), ws.numel(), stream))
+    return outs

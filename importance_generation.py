@@ -7,7 +7,7 @@ prune_imagenet.py / prune_u2netp.py read through --imp_score. The DCT+score arit
 in libdctscore (HIP, gfx950); a GPU is required.
 
 Extra, opt-in flags: --synthetic (seeded synthetic batches; also lifts the need for a
-checkpoint), --input_size, --seed, --single_sweep, --device_accumulate. Multi-GPU: launch with
+checkpoint), --input_size, --seed, --single_sweep, --device_accumulate, --deferred. Multi-GPU: launch with
 `python -m torch.distributed.run --nproc-per-node G importance_generation.py ...` — hook points
 are sharded over the ranks and rank 0 writes the files.
 """
@@ -37,6 +37,8 @@ def parse_args(argv=None):
     parser.add_argument("--seed", type=int, default=0)
     parser.add_argument("--single_sweep", action="store_true", help="score every hook point in one sweep")
     parser.add_argument("--device_accumulate", action="store_true", help="keep the running mean on the GPU")
+    parser.add_argument("--deferred", action="store_true",
+                        help="single sweep, one scoring launch per tile shape per batch (implies the two above)")
     return parser.parse_args(argv)
 
 
@@ -87,7 +89,7 @@ def main(argv=None):
     net = net.to(dev)
 
     harness.imp_score(net, args, single_sweep=args.single_sweep,
-                      accumulate="device" if args.device_accumulate else "host")
+                      accumulate="device" if args.device_accumulate else "host", deferred=args.deferred)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -138,6 +138,23 @@ int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float
                        void* stream);
 
 /*
+ * dcts_energy_f32 for `count` tensors of the SAME tile shape (H, W) in one launch (chunks of 32):
+ * the single-sweep harness scores every hooked tensor of a shape at the end of the forward pass,
+ * and CIFAR-sized layers are too small to fill the GPU one launch at a time. Rows must be dense
+ * (strideH == W, strideW == 1). `items` is a HOST array, copied into the kernel arguments.
+ * Shapes without a codelet kernel are processed tensor by tensor (same result, no batching);
+ * `workspace` must then cover the largest item (dcts_workspace_bytes).
+ */
+typedef struct dcts_tensor_item {
+  const float* x;   /* [N, C_total, H, W] view: element (n,c,h,w) at x[n*strideN + c*strideC + h*W + w] */
+  float* out_nc;    /* [N, c_count] */
+  int64_t N, C_total, strideN, strideC;
+  int32_t c_begin, c_count;
+} dcts_tensor_item;
+int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t H, int64_t W,
+                          int32_t pad_front_if_odd, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Device-side form of the running-mean update of get_feature_hook, utils/common.py:273-277:
  *   c = sum_n energy_nc[n, :]
  *   feature_result = (feature_result * total_before + c) / (total_before + N)

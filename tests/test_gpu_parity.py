@@ -266,3 +266,26 @@ def test_empty_and_oversize_are_errors():
         dpa.energy_nc(torch.zeros(1, 1, 513, 513).cuda())
     with pytest.raises(DctScoreError):
         dpa.energy_nc(torch.zeros(1, 1, 224, 224).cuda(), algo=dpa.ALGO_CODELET)
+
+
+@pytest.mark.parametrize("n,pad", [(8, False), (7, False), (9, True), (14, False), (32, False), (56, False), (24, False),
+                                   (128, False)])
+def test_energy_multi_matches_single_calls(n, pad):
+    """dcts_energy_multi_f32: many tensors of one tile shape in one launch == one call per tensor
+    (bitwise), including channel slices, batch-strided views and more than 32 items (chunking)."""
+    base = [synth(2 + i % 3, 5 + 7 * (i % 4), n, n, 400 + i) for i in range(5 if n >= 56 else 37)]
+    items = []
+    for i, x in enumerate(base):
+        xc = x.cuda()
+        if i % 3 == 0:
+            items.append((xc, 0, None))
+        elif i % 3 == 1:
+            items.append((xc, 2, 3))
+        else:
+            items.append((xc[::2], 1, None))
+    outs = dpa.energy_multi(items, pad_front_if_odd=pad)
+    assert len(outs) == len(items)
+    for (x, cb, cc), got in zip(items, outs):
+        ref = dpa.energy_nc(x, c_begin=cb, c_count=cc, pad_front_if_odd=pad)
+        assert torch.equal(got, ref)
+        check(x.cpu(), got, c_begin=cb, c_count=cc, pad_front_if_odd=pad)

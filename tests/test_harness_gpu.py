@@ -84,3 +84,13 @@ def test_hook_scores_vs_oracle_on_same_activations(name, tmp_path):
         nz = ref > 0
         assert torch.all(got[~nz] == 0)
         assert ((got[nz] - ref[nz]).abs() / ref[nz]).max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["vgg_16_bn", "resnet_56", "densenet_40", "googlenet", "u2netp"])
+def test_deferred_multi_launch_mode_equals_per_hook(name, tmp_path):
+    """deferred=True: hooks keep references, one dcts_energy_multi_f32 launch per tile shape per batch."""
+    base, lines0, _ = run_harness(name, tmp_path / "a", device="cuda")
+    out, lines, _ = run_harness(name, tmp_path / "b", device="cuda", deferred=True)
+    assert lines == lines0 and sorted(out) == sorted(base)
+    for k in base:
+        np.testing.assert_allclose(out[k], base[k], rtol=1e-4, atol=1e-6 * float(base[k].max()), err_msg=k)
