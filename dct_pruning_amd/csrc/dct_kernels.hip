@@ -767,13 +767,28 @@ __device__ unsigned long long g_fused_stamps[16][16];
 #define DCTS_STAMP(slot) ((void)0)
 #endif
 
+// sum of a map's per-wave partials in fixed order (wave 0, lane 0) and the final scale
+template <int M, int L, int ROLE>
+__device__ __forceinline__ void fused_finish(lds_ptr partials, int slot, long long m, float* __restrict__ out,
+                                             int lane) {
+  constexpr int S = 1 << L, N = M << L;
+  if (ROLE == 0 && lane == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < S; ++i) t += partials[slot * S + i];
+    constexpr float sc = float(4.0 / (double(N) * double(N)));
+    out[m] = t * sc;
+  }
+}
+
 template <int M, int L, int ROLE>
 __device__ __forceinline__ void fused_body(const float* __restrict__ x, long long map_stride, long long nmaps,
                                            float* __restrict__ out, lds_ptr lds, lds_ptr partials, int lane) {
   using Cfg = FusedCfg<M, L>;
   constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, STRIPS = Cfg::STRIPS, COLS = Cfg::COLS, KPR = Cfg::KPR,
                 RPR = Cfg::RPR, ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, BUF = Cfg::BUF;
-  int cur = 0;
+  int cur = 0, pslot = 0, pending_slot = 0;
+  long long pending_m = -1;
   long long m = blockIdx.x;
 #ifdef DCTS_FUSED_STAMPS
   unsigned long long acc_[16] = {}, last_;
@@ -790,6 +805,12 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this strip has landed
       DCTS_STAMP(0);
       __syncthreads();                                   // ... for everyone; the other buffer is free
+      if constexpr (s == 0) {
+        if (pending_m >= 0) {
+          fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane);
+          pending_m = -1;
+        }
+      }
       DCTS_STAMP(1);
       const lds_ptr buf = lds + cur * BUF;
       const lds_ptr nxt = lds + (cur ^ 1) * BUF;
@@ -869,16 +890,17 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
     // ---- reduce: lanes -> wave -> workgroup, fixed order -------------------------------------
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) e += __shfl_down(e, off, 64);
-    if (lane == 0) partials[ROLE] = e;
-    __syncthreads();
-    if (ROLE == 0 && lane == 0) {
-      float t = 0.f;
-#pragma unroll
-      for (int i = 0; i < S; ++i) t += partials[i];
-      constexpr float sc = float(4.0 / (double(N) * double(N)));
-      out[m] = t * sc;
-    }
+    // the workgroup-level sum is deferred past the next barrier the loop executes anyway (the first
+    // one of the next map, or the one after the loop): partials are double-buffered by map parity
+    if (lane == 0) partials[pslot * S + ROLE] = e;
+    pending_m = m;
+    pending_slot = pslot;
+    pslot ^= 1;
     DCTS_STAMP(13);
+  }
+  if (pending_m >= 0) {
+    __syncthreads();
+    fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane);
   }
 #ifdef DCTS_FUSED_STAMPS
   if (lane == 0)
@@ -909,7 +931,7 @@ __global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_s
                                                               long long nmaps, float* __restrict__ out) {
   using Cfg = FusedCfg<M, L>;
   __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF];
-  __shared__ float partials[Cfg::S];
+  __shared__ float partials[2 * Cfg::S];
   fused_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63,
                        std::make_integer_sequence<int, Cfg::S>{});
 }
