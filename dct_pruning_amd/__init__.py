@@ -11,6 +11,7 @@ from .ops import (  # noqa: F401
     ALGO_CODELET,
     ALGO_DIRECT,
     ALGO_FUSED,
+    ALGO_PIPE,
     ALGO_PREFETCH,
     ALGO_SPLIT,
     batch_sum,
@@ -20,4 +21,4 @@ from .ops import (  # noqa: F401
     has_codelet,
 )
 
-__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED"]
+__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE"]

@@ -4,5 +4,20 @@
 // the odd pad) and its 320-crop family 40/20/10; 64 and 48 are the natural power-of-two /
 // 3*2^k fillers.
 #pragma once
+#ifdef DCTS_DEV_FAST  // development builds: a handful of instantiations, seconds instead of minutes
+#define DCTS_CODELET_SIZES(X) X(8)
+#define DCTS_SPLIT_TABLE(X) X(128, 32, 2) X(224, 28, 3)
+#ifndef DCTS_FUSED_TABLE
+#ifndef DCTS_DEV_M224
+#define DCTS_DEV_M224 14
+#define DCTS_DEV_L224 4
+#endif
+#define DCTS_FUSED_TABLE(X) X(128, 16, 3) X(224, 14, 4)
+#endif
+#ifndef DCTS_PIPE_TABLE
+#define DCTS_PIPE_TABLE(X) X(128, 16, 3) X(224, DCTS_DEV_M224, DCTS_DEV_L224)
+#endif
+#else
 #define DCTS_CODELET_SIZES(X) \
   X(2) X(4) X(7) X(8) X(9) X(10) X(14) X(16) X(18) X(20) X(28) X(32) X(36) X(40) X(48) X(56) X(64)
+#endif

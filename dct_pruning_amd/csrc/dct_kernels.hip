@@ -521,8 +521,59 @@ struct NoHook {
 // loads of the next strip between butterflies instead of issuing them in one burst (a burst of
 // 8 x 8 KiB per CU back-pressures the issue: stamps showed 470 cycles per load instruction)
 template <int M, int L, class Hook = NoHook>
-__device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lane_ok, int lane, int wave,
-                                                  Hook hook = Hook{}) {
+__device__ __forceinline__ void split_butterflies_pk(lds_ptr base, int rs, bool lane_ok, int lane, int wave,
+                                                     Hook hook = Hook{}) {
+  // Two samples p, p+1 per iteration as the halves of packed-f32 registers (v_pk_add/mul/fma_f32:
+  // two results per issue slot): the network is the same for every p, only the rotation constants
+  // differ. This phase is VALU-issue-bound, and the pairs halve its instruction count.
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int S = 1 << L;
+  constexpr int NPAIR = (M + 1) / 2;
+  constexpr RolePlan<L> plan{};
+  const RotTable<M, L>& tab = kRotTable<M, L>;
+  lds_ptr colp = base + (lane_ok ? lane : 0);
+  for (int j = wave; j < NPAIR; j += S) {
+    const int p = 2 * j;                   // even: (-1)^p = +1, (-1)^(p+1) = -1
+    const bool two = (M % 2 == 0) || (p + 1 < M);
+    const int p1 = two ? p + 1 : p;
+    f2 y[S];
+    dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int s = decltype(i)::value;
+      const int row0 = (s % 2 == 0) ? s * M + p : s * M + M - 1 - p;
+      const int row1 = (s % 2 == 0) ? s * M + p1 : s * M + M - 1 - p1;
+      y[s] = f2{colp[row0 * rs], colp[row1 * rs]};
+    });
+    dcts::static_for<plan.NOPS>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int o = decltype(i)::value;
+      constexpr int a = plan.op_a[o], bb = plan.op_b[o], r = plan.op_rot[o];
+      const f2 ya = y[a], yb = y[bb];
+      if constexpr (r < 0) {
+        y[a] = ya + yb;
+        y[bb] = ya - yb;
+      } else {
+        constexpr float k0 = RotTable<M, L>::sign0(r);
+        const f2 c = f2{tab.c[r][p], tab.c[r][p1]}, sn = f2{tab.s[r][p], tab.s[r][p1]};
+        const f2 cs = f2{k0 * c.x, -k0 * c.y}, ss = f2{k0 * sn.x, -k0 * sn.y};  // sign of the second output folded in
+        y[a] = ya * c + yb * sn;
+        y[bb] = yb * cs - ya * ss;
+      }
+    });
+    if (lane_ok) {
+      dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int s = decltype(i)::value;
+        const int row0 = (s % 2 == 0) ? s * M + p : s * M + M - 1 - p;
+        const int row1 = (s % 2 == 0) ? s * M + p1 : s * M + M - 1 - p1;
+        colp[row0 * rs] = y[s].x;
+        if (two) colp[row1 * rs] = y[s].y;
+      });
+    }
+    hook();
+  }
+}
+
+template <int M, int L, class Hook = NoHook>
+__device__ __forceinline__ void split_butterflies_1(lds_ptr base, int rs, bool lane_ok, int lane, int wave,
+                                                    Hook hook = Hook{}) {
   constexpr int S = 1 << L;
   constexpr RolePlan<L> plan{};
   const RotTable<M, L>& tab = kRotTable<M, L>;
@@ -558,6 +609,19 @@ __device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lan
     }
     hook();
   }
+}
+
+// The packed form halves the instruction count but also the number of busy waves, and doubles the
+// 2^L live samples. Measured: +3..5 % in the two-launch pass kernel (288, 320), -2..8 % in the
+// eight-wave fused kernels (too few waves left to hide LDS latency), spills in the sixteen-wave
+// ones. So only k_pass1d asks for it.
+template <int M, int L, class Hook = NoHook, bool PACK = false>
+__device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lane_ok, int lane, int wave,
+                                                  Hook hook = Hook{}) {
+  if constexpr (PACK)
+    split_butterflies_pk<M, L>(base, rs, lane_ok, lane, wave, hook);
+  else
+    split_butterflies_1<M, L>(base, rs, lane_ok, lane, wave, hook);
 }
 
 // role r's M-point transform of one column of the butterflied image: gathers the role's input
@@ -680,13 +744,53 @@ __global__ __launch_bounds__((64 << L), (split_waves_per_simd<M>())) void k_pass
   __syncthreads();
 
   const lds_ptr lds3 = (lds_ptr)lds;
-  split_butterflies<M, L>(lds3, SW, lane < SW, lane, wave);
+  split_butterflies<M, L, NoHook, true>(lds3, SW, lane < SW, lane, wave);
   __syncthreads();
 
   float* t_b = FINAL ? nullptr : t + b * (long long)N * N;
   float* part = partial + (long long)blockIdx.x * Cfg::ROLES + wave;
   split_dispatch<M, L, FINAL>(wave, lds3, t_b, lds3, strip, lane, part,
                               std::make_integer_sequence<int, Cfg::ROLES>{});
+}
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() carries a workgroup-scope fence
+// over ALL address spaces: the compiler puts s_waitcnt vmcnt(0) in front of every s_barrier, i.e.
+// each barrier also waits for every direct-to-LDS load still in flight and the prefetch of the
+// next strip is drained five times per step. The data those loads bring is published by the
+// explicit s_waitcnt vmcnt(0) + barrier at the top of pass 1.
+// (A fence restricted to the "local" address space still waits vmcnt(0): the loads in flight write
+// LDS. Hence the raw instruction pair; LDS operations of a wave complete in order.)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Opaque copy of a lane-dependent value: everything derived from the copy has to be recomputed where
+// it is used. Without it LLVM hoists the address arithmetic of every phase (dump offsets per strip,
+// column pointers of both buffers, shuffle indices, ...) out of the persistent loop and keeps some
+// twenty loop-invariant VGPRs alive next to the parked tile: spills, and a scratch reload's
+// s_waitcnt vmcnt(0) also waits for every direct-to-LDS load in flight.
+__device__ __forceinline__ int launder(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// wave64 sum by DPP within rows of 16 lanes, then the four row totals in fixed order: no index
+// registers (ds_bpermute needs one per offset), result uniform across the wave
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float a, auto ctrl) DCTS_LAMBDA_INLINE {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -738,9 +842,31 @@ struct FusedStage {
     const int q = qbase + lane;
     const int row = q >> 4, col = (q & 15) << 2;
     if (q < NQUADS && strip * SW + col < N) {
-      const float* g = in_b + (long long)row * N + strip * SW + col;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+      // uniform base + 32-bit lane offset: the saddr form needs one address VGPR instead of two
+      const float* base = in_b + strip * SW;
+      const unsigned off = (unsigned)(row * N + col);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
                                        (__attribute__((address_space(3))) void*)(buf + 4 * qbase), 16, 0, 0);
+    }
+  }
+  // The same load as a raw instruction. The compiler tracks direct-to-LDS loads it knows about and
+  // puts s_waitcnt vmcnt(0) in front of the next LDS access that may alias the destination; its
+  // alias information does not survive this kernel's pointer arithmetic, so EVERY following
+  // ds_read/ds_write waited for the prefetch to land (one memory round trip per instalment). The
+  // pipelined kernel orders these loads itself: s_waitcnt vmcnt(0) + barrier before the strip is read.
+  static __device__ __forceinline__ void piece_raw(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
+                                                   int wave, int it) {
+    const int qbase = it * THREADS + wave * 64;  // wave-uniform
+    const int q = qbase + lane;
+    const int row = q >> 4, col = (q & 15) << 2;
+    if (q < NQUADS && strip * SW + col < N) {
+      const float* base = in_b + strip * SW;
+      const unsigned off = (unsigned)(row * N + col) * 4u;  // bytes
+      const unsigned dst = (unsigned)(unsigned long long)(buf + 4 * qbase);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :
+                   : "s"(dst), "v"(off), "s"(base)
+                   : "memory", "m0");
     }
   }
   static __device__ __forceinline__ void all(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
@@ -794,7 +920,11 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
   unsigned long long acc_[16] = {}, last_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
-  if (m < nmaps) FusedStage<M, L>::all(x + m * map_stride, 0, lds, lane, ROLE);
+  if (m < nmaps) {
+#pragma unroll
+    for (int it = 0; it < FusedStage<M, L>::PIECES; ++it)
+      FusedStage<M, L>::piece_raw(x + m * map_stride, 0, lds, lane, ROLE, it);
+  }
   for (; m < nmaps; m += gridDim.x) {
     const float* in_b = x + m * map_stride;
     float parked[STRIPS][M];
@@ -804,7 +934,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       DCTS_STAMP(11);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this strip has landed
       DCTS_STAMP(0);
-      __syncthreads();                                   // ... for everyone; the other buffer is free
+      lds_barrier();                                   // ... for everyone; the other buffer is free
       if constexpr (s == 0) {
         if (pending_m >= 0) {
           fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane);
@@ -823,14 +953,14 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       auto trickle = [&]() DCTS_LAMBDA_INLINE {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          if (piece < FusedStage<M, L>::PIECES) FusedStage<M, L>::piece(nsrc, nstrip, nxt, lane, ROLE, piece++);
+          if (piece < FusedStage<M, L>::PIECES) FusedStage<M, L>::piece_raw(nsrc, nstrip, nxt, lane, ROLE, piece++);
       };
       const bool act = s * SW + lane < N;  // lane < 64 == SW always
       DCTS_STAMP(2);
       split_butterflies<M, L>(buf, SW, act, lane, ROLE, trickle);
-      while (piece < FusedStage<M, L>::PIECES) FusedStage<M, L>::piece(nsrc, nstrip, nxt, lane, ROLE, piece++);
+      while (piece < FusedStage<M, L>::PIECES) FusedStage<M, L>::piece_raw(nsrc, nstrip, nxt, lane, ROLE, piece++);
       DCTS_STAMP(3);
-      __syncthreads();
+      lds_barrier();
       DCTS_STAMP(4);
       split_role_transform<M, L, ROLE>(buf + (act ? lane : 0), SW, parked[s]);
       DCTS_STAMP(5);
@@ -842,7 +972,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
     dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(ir)::value;
       DCTS_STAMP(11);
-      __syncthreads();  // previous readers of blk are done
+      lds_barrier();  // previous readers of blk are done
       DCTS_STAMP(6);
       if constexpr (Cfg::BALANCED) {
         dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
@@ -870,12 +1000,12 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
         });
       }
       DCTS_STAMP(7);
-      __syncthreads();
+      lds_barrier();
       DCTS_STAMP(8);
       const bool act = lane < COLS;
       split_butterflies<M, L>(blk, RW, act, lane, ROLE);
       DCTS_STAMP(9);
-      __syncthreads();
+      lds_barrier();
       DCTS_STAMP(10);
       float o[M];
       split_role_transform<M, L, ROLE>(blk + (act ? lane : 0), RW, o);
@@ -899,7 +1029,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
     DCTS_STAMP(13);
   }
   if (pending_m >= 0) {
-    __syncthreads();
+    lds_barrier();
     fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane);
   }
 #ifdef DCTS_FUSED_STAMPS
@@ -934,6 +1064,255 @@ __global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_s
   __shared__ float partials[2 * Cfg::S];
   fused_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63,
                        std::make_integer_sequence<int, Cfg::S>{});
+}
+
+// ---------------------------------------------------------------------------------------
+// pipelined fused kernel: pass 2 of map m interleaved with pass 1 of map m+1
+// ---------------------------------------------------------------------------------------
+// The fused kernel above streams a map in (pass 1, HBM-bound), then transforms the parked tile
+// (pass 2, no HBM traffic at all): the two halves alternate and neither the memory system nor the
+// VALUs are ever busy for more than half of the time. Here one step = pass-2 round r of the
+// previous map followed by pass-1 strip r of the current one, so the direct-to-LDS loads of strip
+// r+1 are in flight for a whole step (both halves) and the kernel becomes VALU-issue-bound.
+// Registers: every round dumps KPR coefficients of every wave's parked rows (the balanced dump),
+// which frees exactly the registers the next strip's M outputs need, so the parked set never
+// exceeds one tile: slots P[T][T][KPR], T = strips = rounds. A map parked with layout 0 keeps
+// T[strip s][coef k] in P[k/KPR][s][k%KPR], layout 1 in P[s][k/KPR][k%KPR]: round r of a
+// layout-0 map frees P[r][*][*], which is where strip r of the next map (layout 1) goes, and vice
+// versa; maps alternate layouts, the loop body is unrolled over the two parities.
+// LDS: two buffers. Step k transforms the staged strip in B[k%2]; the pass-2 image of that step
+// lives in B[(k+1)%2], which then receives strip k+1 while B[k%2] is transformed.
+template <int M, int L>
+struct PipeCfg {
+  static constexpr int N = M << L, S = 1 << L, SW = 64;
+  static constexpr int T = (N + SW - 1) / SW;
+  static constexpr int KPR = 64 / S;
+  static constexpr int RW = 65;  // pass-2 image row stride: 64 columns, odd
+  static constexpr int BUF = N * RW;
+  static_assert((M + KPR - 1) / KPR == T, "rounds == strips");
+  static_assert(S <= 16 && N % 4 == 0, "shape");
+  // Register relief: NP of the M outputs of strip s are parked in LDS instead (one dword per thread
+  // and value, conflict-free), namely the last NP real coefficients of round s. Those are dumped
+  // in step s of the next map, before strip s of that map overwrites them, so one copy is enough.
+  static constexpr int LDS_FLOATS = 160 * 1024 / 4 - 2 * S - 64;
+  static constexpr int last_real = M - (T - 1) * KPR;  // real coefficients in the last round
+  static constexpr int NP_FIT = (LDS_FLOATS - 2 * BUF) / (T * 64 * S);
+  static constexpr int NP = NP_FIT < 0 ? 0 : (NP_FIT > 2 ? 2 : NP_FIT) > last_real ? last_real : (NP_FIT > 2 ? 2 : NP_FIT);
+  static constexpr int nreal(int r) { return r == T - 1 ? last_real : KPR; }
+  // index (0..NP-1) of coefficient k of strip s in the LDS park, or -1 if it stays in a register
+  static constexpr int park_index(int s, int k) {
+    if (k / KPR != s) return -1;
+    const int c = k % KPR, first = nreal(s) - NP;
+    return (c >= first && c < nreal(s)) ? c - first : -1;
+  }
+};
+
+template <int PAR, int SI, int K, int T, int KPR>
+__device__ __forceinline__ float& pipe_slot(float (&P)[T][T][KPR]) {
+  if constexpr (PAR == 0)
+    return P[K / KPR][SI][K % KPR];
+  else
+    return P[SI][K / KPR][K % KPR];
+}
+
+template <int M, int L, int ROLE>
+__device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long map_stride, long long nmaps,
+                                          float* __restrict__ out, lds_ptr buf0, lds_ptr buf1, lds_ptr parkbuf, lds_ptr partials,
+                                          int lane_in) {
+  using Cfg = PipeCfg<M, L>;
+  using Stage = FusedStage<M, L>;
+  constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, T = Cfg::T, KPR = Cfg::KPR, RW = Cfg::RW, BUF = Cfg::BUF;
+  float P[T][T][KPR];
+  const lds_ptr park = parkbuf + (ROLE * 64 + lane_in);  // [T * NP][64 * S]
+  long long m_cur = blockIdx.x, m_prev = -1, pending_m = -1;
+  int pslot = 0, pending_slot = 0;
+#ifdef DCTS_FUSED_STAMPS
+  unsigned long long acc_[16] = {}, last_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
+  if (m_cur < nmaps) {
+#pragma unroll
+    for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(x + m_cur * map_stride, 0, buf0, lane_in, ROLE, it);
+  }
+
+  // The direct-to-LDS loads of a strip are issued in four instalments spread over one whole step
+  // (pass-1 butterflies and transform of the previous strip, then the dump and the butterflies of
+  // the following pass-2 round): a wave stalls on such an instruction while the CU's memory queue
+  // is full, and with all of a strip's loads in one phase every wave sat out that stall at the
+  // phase's barrier (stamps: 4.8k of a step's 13k cycles) while the queue idled in the other four.
+  auto issue = [&](const float* src, int strip, lds_ptr buf, auto slot) DCTS_LAMBDA_INLINE {
+#pragma unroll
+    for (int it = decltype(slot)::value; it < Stage::PIECES; it += 4)
+      Stage::piece_raw(src, strip, buf, launder(lane_in), ROLE, it);
+  };
+  using Q0 = std::integral_constant<int, 0>;
+  using Q1 = std::integral_constant<int, 1>;
+  using Q2 = std::integral_constant<int, 2>;
+  using Q3 = std::integral_constant<int, 3>;
+  auto iteration = [&](auto par, auto hp, auto hc) DCTS_LAMBDA_INLINE {
+    constexpr int PAR = decltype(par)::value;  // layout of the previous map; the current one gets 1 - PAR
+    constexpr bool have_prev = decltype(hp)::value, have_cur = decltype(hc)::value;
+    const float* in_b = x + (have_cur ? m_cur : 0) * map_stride;
+    float e = 0.f;
+    dcts::static_for<T>([&](auto ir) DCTS_LAMBDA_INLINE {
+      constexpr int r = decltype(ir)::value;
+      constexpr int k = PAR * T + r;
+      // The two buffers are separate __shared__ objects, statically selected: that is what lets the
+      // compiler see that LDS reads of one do not alias direct-to-LDS loads in flight to the other.
+      // With one array and offsets it put s_waitcnt vmcnt(0) in front of the first LDS access after
+      // every such load: a full memory round trip per instalment.
+      const lds_ptr dat = (k % 2) ? buf1 : buf0;  // strip r of the current map (landing / landed)
+      const lds_ptr img = (k % 2) ? buf0 : buf1;  // pass-2 image of this step, then strip r+1
+      if constexpr (have_prev) {
+        DCTS_STAMP(12);
+        lds_barrier();  // the strip that lived in img has been consumed by everyone
+        DCTS_STAMP(0);
+        if constexpr (r == 0) {
+          if (pending_m >= 0) {
+            fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane_in);
+            pending_m = -1;
+          }
+        }
+        if constexpr (have_cur) issue(in_b, r, dat, Q2{});
+        int lane = launder(lane_in);
+        dcts::static_for<T>([&](auto is) DCTS_LAMBDA_INLINE {
+          constexpr int s = decltype(is)::value;
+          const int line = s * SW + lane;
+          const int off = (line < N ? line : 0) * RW + ROLE * KPR;
+          dcts::static_for<KPR>([&](auto ic) DCTS_LAMBDA_INLINE {
+            constexpr int c = decltype(ic)::value;
+            if constexpr (r * KPR + c < M) {
+              constexpr int pi = Cfg::park_index(s, r * KPR + c);
+              if constexpr (pi >= 0) {
+                const float v = park[(s * Cfg::NP + pi) * (64 * S)];
+                if (line < N) img[off + c] = v;
+              } else {
+                if (line < N) img[off + c] = pipe_slot<PAR, s, r * KPR + c>(P);
+              }
+            } else {
+              if (line < N) img[off + c] = 0.f;  // padding column: contributes exactly zero energy
+            }
+          });
+        });
+        DCTS_STAMP(1);
+        lds_barrier();
+        DCTS_STAMP(2);
+        if constexpr (have_cur) issue(in_b, r, dat, Q3{});
+        lane = launder(lane_in);
+        split_butterflies<M, L>(img, RW, true, lane, ROLE);
+        DCTS_STAMP(3);
+        lds_barrier();
+        DCTS_STAMP(4);
+        lane = launder(lane_in);
+        float o[M];
+        split_role_transform<M, L, ROLE>(img + lane, RW, o);
+        float er = 0.f;
+        dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+          constexpr int kk = decltype(ik)::value;
+          er = fmaf(o[kk], o[kk], er);
+        });
+        asm volatile("" : "+v"(er));
+        e += er;
+        DCTS_STAMP(5);
+      }
+      if constexpr (have_cur) {
+        DCTS_STAMP(12);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this strip have landed
+        DCTS_STAMP(6);
+        lds_barrier();                                   // ... everyone's; img has been consumed
+        DCTS_STAMP(7);
+        const bool more = (r + 1 < T) || (m_cur + gridDim.x < nmaps);
+        const float* nsrc = (r + 1 < T) ? in_b : x + (m_cur + gridDim.x) * map_stride;
+        constexpr int nstrip = (r + 1 < T) ? r + 1 : 0;
+        // the step that transforms the next strip starts with a pass-2 round (which issues the other
+        // two instalments) unless this is the first map of the workgroup
+        constexpr bool next_has_p2 = have_prev || (r + 1 == T);
+        if (more) {
+          issue(nsrc, nstrip, img, Q0{});
+          if constexpr (!next_has_p2) issue(nsrc, nstrip, img, Q2{});
+        }
+        int lane = launder(lane_in);
+        const bool act = r * SW + lane < N;
+        split_butterflies<M, L>(dat, SW, act, lane, ROLE);
+        DCTS_STAMP(8);
+        lds_barrier();
+        DCTS_STAMP(9);
+        if (more) {
+          issue(nsrc, nstrip, img, Q1{});
+          if constexpr (!next_has_p2) issue(nsrc, nstrip, img, Q3{});
+        }
+        lane = launder(lane_in);
+        float o[M];
+        split_role_transform<M, L, ROLE>(dat + (act ? lane : 0), SW, o);
+        dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+          constexpr int kk = decltype(ik)::value;
+          // pin the codelet here: LLVM otherwise sinks its arithmetic down to the dump one map later
+          // (the first use of the outputs) and keeps the inputs and half-finished temporaries alive
+          constexpr int pi = Cfg::park_index(r, kk);
+          if constexpr (pi >= 0) {
+            park[(r * Cfg::NP + pi) * (64 * S)] = o[kk];
+          } else {
+            asm volatile("" : "+v"(o[kk]));
+            pipe_slot<1 - PAR, r, kk>(P) = o[kk];
+          }
+        });
+        DCTS_STAMP(10);
+      }
+    });
+    if constexpr (have_prev) {
+      e = wave_sum_dpp(e);
+      if (lane_in == 0) partials[pslot * S + ROLE] = e;
+      pending_m = m_prev;
+      pending_slot = pslot;
+      pslot ^= 1;
+      DCTS_STAMP(11);
+    }
+    m_prev = have_cur ? m_cur : -1;
+    m_cur += gridDim.x;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // every workgroup owns at least one map (grid <= nmaps): prologue, steady pairs, epilogue
+  iteration(I0{}, std::false_type{}, std::true_type{});
+  for (;;) {
+    if (m_cur >= nmaps) {
+      iteration(I1{}, std::true_type{}, std::false_type{});
+      break;
+    }
+    iteration(I1{}, std::true_type{}, std::true_type{});
+    if (m_cur >= nmaps) {
+      iteration(I0{}, std::true_type{}, std::false_type{});
+      break;
+    }
+    iteration(I0{}, std::true_type{}, std::true_type{});
+  }
+  if (pending_m >= 0) {
+    lds_barrier();
+    fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane_in);
+  }
+#ifdef DCTS_FUSED_STAMPS
+  if (lane_in == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_fused_stamps[ROLE][i], acc_[i]);
+#endif
+}
+
+template <int M, int L, int... R>
+__device__ __forceinline__ void pipe_dispatch(int role, const float* x, long long map_stride, long long nmaps,
+                                              float* out, lds_ptr buf0, lds_ptr buf1, lds_ptr park, lds_ptr partials,
+                                              int lane, std::integer_sequence<int, R...>) {
+  ((role == R ? pipe_body<M, L, R>(x, map_stride, nmaps, out, buf0, buf1, park, partials, lane) : (void)0), ...);
+}
+
+template <int M, int L>
+__global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_split_pipe(const float* __restrict__ x, long long map_stride,
+                                                             long long nmaps, float* __restrict__ out) {
+  using Cfg = PipeCfg<M, L>;
+  __shared__ __attribute__((aligned(16))) float buf0[Cfg::BUF];
+  __shared__ __attribute__((aligned(16))) float buf1[Cfg::BUF];
+  __shared__ float park[Cfg::T * Cfg::NP * 64 * Cfg::S > 0 ? Cfg::T * Cfg::NP * 64 * Cfg::S : 1];
+  __shared__ float partials[2 * Cfg::S];
+  pipe_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)park,
+                      (lds_ptr)partials, threadIdx.x & 63, std::make_integer_sequence<int, Cfg::S>{});
 }
 
 // out[b] = scale * sum of the map's ROLES*STRIPS partials, fixed order
@@ -1250,9 +1629,11 @@ int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipS
 
 // tile edges served by the split family: X(N, M, L) with N = M << L. L = 3 (eight M-point roles)
 // where the four-role codelets would be too register-hungry for more than 1-2 waves per SIMD.
+#ifndef DCTS_SPLIT_TABLE
 #define DCTS_SPLIT_TABLE(X)                                                              \
   X(72, 18, 2) X(80, 20, 2) X(112, 28, 2) X(128, 32, 2) X(144, 36, 2) X(160, 40, 2)      \
   X(224, 28, 3) X(256, 32, 3) X(288, 36, 3) X(320, 40, 3)
+#endif
 
 bool has_split(long long HP, long long WP) {
   if (HP != WP) return false;
@@ -1325,8 +1706,10 @@ int launch_split(const MapGeom& g, float* out, void* workspace, hipStream_t st) 
 // tiles whose intermediate fits the register file of one CU: single fused launch X(N, M, L).
 // (M, L) per edge is the fastest measured factorisation (e.g. 224: 28x8 roles 19 %, 14x16 roles 26 %;
 // 128: 16x8 38 %, 32x4 35 %, 8x16 22 %; 288 = 18x16 spills at 128 VGPRs and loses to two launches)
+#ifndef DCTS_FUSED_TABLE
 #define DCTS_FUSED_TABLE(X) \
   X(72, 9, 3) X(80, 10, 3) X(112, 14, 3) X(128, 16, 3) X(144, 18, 3) X(160, 10, 4) X(224, 14, 4) X(256, 16, 4)
+#endif
 
 bool has_fused(long long N) {
 #define DCTS_CASE(N_, M_, L_) \
@@ -1359,6 +1742,48 @@ int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
     return launch_fused<M_, L_>(g, out, st);
   switch (N) {
     DCTS_FUSED_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+
+// pipelined variant X(N, M, L)
+#ifndef DCTS_PIPE_TABLE
+// (measured against the fused kernel, % of 8 TB/s: 128: 49.2 vs 46.9, 224: 36.8 vs 33.1; it loses
+// where the balanced dump pads much (72, 80, 144, 160) or spills (256), and ties at 112)
+#define DCTS_PIPE_TABLE(X) X(128, 16, 3) X(224, 14, 4)
+#endif
+
+bool has_pipe(long long N) {
+#define DCTS_CASE(N_, M_, L_) \
+  if (N == N_) return true;
+  DCTS_PIPE_TABLE(DCTS_CASE)
+#undef DCTS_CASE
+  return false;
+}
+
+template <int M, int L>
+int launch_pipe(const MapGeom& g, float* out, hipStream_t st) {
+  const float* x0 = g.x + (long long)g.c_begin * g.strideC;
+  static const int per_cu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split_pipe<M, L>, 64 << L, 0) != hipSuccess || n < 1)
+      n = 1;
+    return n;
+  }();
+  const long long cap = (long long)kNumCU * per_cu;
+  const long long grid = g.nmaps < cap ? g.nmaps : cap;
+  hipLaunchKernelGGL((k_split_pipe<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, x0, g.strideC, g.nmaps, out);
+  return (int)hipGetLastError();
+}
+
+int dispatch_pipe(int N, const MapGeom& g, float* out, hipStream_t st) {
+#define DCTS_CASE(N_, M_, L_) \
+  case N_:                    \
+    return launch_pipe<M_, L_>(g, out, st);
+  switch (N) {
+    DCTS_PIPE_TABLE(DCTS_CASE)
     default:
       return DCTS_E_UNSUPPORTED;
   }
@@ -1455,7 +1880,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
   if ((algo == DCTS_ALGO_CODELET || algo == DCTS_ALGO_PREFETCH) && !codelet_ok) return DCTS_E_UNSUPPORTED;
   if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET &&
-      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED)
+      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED && algo != DCTS_ALGO_PIPE)
     return DCTS_E_UNSUPPORTED;
   if (codelet_ok && algo != DCTS_ALGO_DIRECT) {
     if constexpr (!STORE) {
@@ -1477,6 +1902,9 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     const bool fused_ok = split_ok && has_fused(HP) &&
                           (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
     if (algo == DCTS_ALGO_FUSED && !fused_ok) return DCTS_E_UNSUPPORTED;
+    const bool pipe_ok = fused_ok && has_pipe(HP);
+    if (algo == DCTS_ALGO_PIPE) return pipe_ok ? dispatch_pipe((int)HP, g, out, st) : DCTS_E_UNSUPPORTED;
+    if (pipe_ok && algo == DCTS_ALGO_AUTO) return dispatch_pipe((int)HP, g, out, st);
     if (fused_ok && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED)) return dispatch_fused((int)HP, g, out, st);
     if (split_ok && algo != DCTS_ALGO_DIRECT) {
       const SplitWs sws = split_ws(g.nmaps, (int)HP);
@@ -1484,7 +1912,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       return dispatch_split((int)HP, g, out, workspace, st);
     }
   } else {
-    if (algo == DCTS_ALGO_SPLIT || algo == DCTS_ALGO_FUSED) return DCTS_E_UNSUPPORTED;
+    if (algo == DCTS_ALGO_SPLIT || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE) return DCTS_E_UNSUPPORTED;
   }
 
   const DirectWs ws = direct_ws(g.nmaps, (int)HP, (int)WP);

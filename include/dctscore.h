@@ -59,8 +59,10 @@ enum {
   DCTS_ALGO_SPLIT = 3,    /* two-launch split-4 codelet passes for edges 4*M (72 ... 320)        */
   DCTS_ALGO_PREFETCH = 4, /* codelet kernel with direct-to-LDS prefetch of the next maps (dense,
                              even-edge square tiles; measured equal to ALGO_CODELET, opt-in)     */
-  DCTS_ALGO_FUSED = 5     /* single-launch split kernel, intermediate tile parked in VGPRs
+  DCTS_ALGO_FUSED = 5,    /* single-launch split kernel, intermediate tile parked in VGPRs
                              (edges 72, 80, 112, 128, 144, 160, 224, 256)                        */
+  DCTS_ALGO_PIPE = 6      /* the fused kernel software-pipelined: pass 2 of one map interleaved
+                             with pass 1 of the next                                             */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */

@@ -90,12 +90,34 @@ def test_fused_sizes(n):
     x = synth(2, 150 if n >= 200 else 700, n, n, 130 + n)
     got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_FUSED)
     check(x, got)
-    assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
+    if n not in PIPE:
+        assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
     assert torch.equal(got, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_FUSED))  # bit-reproducible
     two = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_SPLIT)
     assert rel_err(got.cpu(), two.cpu()) <= 1e-5
     few = synth(1, 3, n, n, 131 + n)  # fewer maps than workgroups
     check(few, dpa.energy_nc(few.cuda(), algo=dpa.ALGO_FUSED))
+
+
+PIPE = [128, 224]
+
+
+@pytest.mark.parametrize("n", PIPE)
+def test_pipelined_sizes(n):
+    """Software-pipelined fused kernel (pass 2 of map m interleaved with pass 1 of map m+1). Map counts
+    chosen so that workgroups run 1, 2, 3 and 4+ maps (prologue / odd and even steady iterations /
+    epilogue with either parity) and so that fewer maps than workgroups also occurs."""
+    for nmaps, seed in [(3, 1), (256, 2), (257, 3), (512, 4), (600, 5), (1100 if n < 200 else 800, 6)]:
+        x = synth(1, nmaps, n, n, 170 + n + seed)
+        got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_PIPE)
+        check(x, got)
+        assert torch.equal(got, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_PIPE))  # bit-reproducible
+        assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
+    dead = synth(1, 300, n, n, 99)
+    dead[0, ::7] = 0.0  # dead channels: exactly +0.0
+    got = dpa.energy_nc(dead.cuda(), algo=dpa.ALGO_PIPE).cpu()
+    assert (got[0, ::7] == 0).all() and not torch.signbit(got[0, ::7]).any()
+    check(dead, got)
 
 
 def test_split_chunking_many_maps():

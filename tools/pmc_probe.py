@@ -27,6 +27,9 @@ for edge, nmaps in [(56, 65536), (28, 262144), (14, 1048576), (7, 4194304), (32,
     t = torch.relu(torch.randn(1, nmaps, edge, edge, device=dev))
     for _ in range(3):
         dpa.energy_nc(t)
+    if edge in (224, 128):  # AUTO runs the pipelined kernel there: profile the plain fused one as well
+        for _ in range(3):
+            dpa.energy_nc(t, algo=dpa.ALGO_FUSED)
     torch.cuda.synchronize()
     del t
 print("probe done")

@@ -51,7 +51,7 @@ def main(dfetch, dwrite):
             if key.startswith("k_energy_codelet_%d_%d_" % (edge, edge)):
                 alg = nmaps * (4 * edge * edge + 4)
         for (mm, ll), (edge, nmaps) in PROBE_FUSED.items():
-            if key == "k_split_fused_%d_%d" % (mm, ll):
+            if key in ("k_split_fused_%d_%d" % (mm, ll), "k_split_pipe_%d_%d" % (mm, ll)):
                 alg = nmaps * (4 * edge * edge + 4)
         out[key] = {"launches": len(vals), "alg_bytes_per_launch": alg,
                     "hbm_over_alg": (((raw * factor if factor else raw) + (wb or 0.0)) / alg) if alg else None,
