@@ -12,6 +12,7 @@ from .ops import (  # noqa: F401
     ALGO_DIRECT,
     ALGO_FUSED,
     ALGO_PIPE,
+    ALGO_LANE,
     ALGO_PREFETCH,
     ALGO_SPLIT,
     batch_sum,
@@ -21,4 +22,4 @@ from .ops import (  # noqa: F401
     has_codelet,
 )
 
-__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE"]
+__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE"]

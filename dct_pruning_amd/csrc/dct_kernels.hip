@@ -31,6 +31,10 @@
 
 namespace {
 
+// LDS pointers stay in address space 3 end to end (see the split family for why)
+using lds_ptr = __attribute__((address_space(3))) float*;
+using lds_cptr = const __attribute__((address_space(3))) float*;
+
 struct MapGeom {
   const float* x;
   long long nmaps;    // N * c_count
@@ -215,6 +219,145 @@ __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_cod
     t = __builtin_amdgcn_readfirstlane(t);
     const MultiItem& item = mg.it[t];
     codelet_group<HP, WP, PAD, false>(item.g, item.out, grp - item.group_begin, my, g1, c, g2, k, act1, act2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// lane-per-map kernels for tiny odd tiles (7x7: the last stage of ResNet-50; 9x9: U2-Net-p)
+// ---------------------------------------------------------------------------------------
+// The codelet kernel above gives a 7x7 map to 7 lanes: 243 VALU instructions per 9 maps, of which
+// 70 are arithmetic (the rest: addressing, the transpose, a segmented reduction over 7 lanes), and
+// every load instruction touches nine 28-byte segments: VALU-issue-bound at 45-50 % of the HBM peak.
+// Here a lane owns a whole map: a wave streams 64 consecutive maps (64*N*N floats, contiguous in
+// memory) into its private LDS slab with direct-to-LDS loads, every lane reads its N*N values
+// (stride N*N floats between lanes: odd, conflict-free), and both DCT passes run in registers with
+// no transpose and no cross-lane reduction: ~9 instructions per map instead of 27. The slab is free
+// as soon as the lanes have read it, so the next group's loads are in flight during the arithmetic.
+// Channel-sliced (non-dense) tensors take per-lane loads into the same arithmetic: same results.
+template <int N>
+struct LaneCfg {
+  static constexpr int NN = N * N;
+  static constexpr int G = 64;                         // maps per wave per iteration
+  static constexpr int SLAB = (G * NN + 3) / 4 * 4;    // floats
+  static constexpr int ITERS = (G * NN / 4 + 63) / 64;  // direct-to-LDS instructions per group
+  static constexpr int WAVES = 2;
+  static_assert(NN % 2 == 1, "lane stride must be odd (bank conflicts) - even tiles use the codelet kernel");
+};
+
+struct LaneGroup {  // wave-uniform description of one group of <= 64 maps
+  const float* src;  // dense: first float of the group
+  float* out;        // &out[m0]
+  long long m0;
+  int nm;            // maps in the group
+  int dense;
+  int item;
+};
+
+template <int N>
+__device__ __forceinline__ void lane_stage(const LaneGroup& gr, lds_ptr my, int lane) {
+  using Cfg = LaneCfg<N>;
+  if (!gr.dense) return;
+  const int nfl = gr.nm * Cfg::NN, nq = nfl >> 2, rem = nfl & 3;
+  // wave-uniform operands, made so explicitly (they derive from the wave index)
+  const unsigned long long sa = reinterpret_cast<unsigned long long>(gr.src);
+  const unsigned long long src = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(sa >> 32)) << 32) |
+                                 (unsigned)__builtin_amdgcn_readfirstlane((int)sa);
+  const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)my);
+#pragma unroll
+  for (int it = 0; it < Cfg::ITERS; ++it) {
+    const int q = it * 64 + lane;
+    if (q < nq) {
+      const unsigned dst = base + it * 1024;
+      const unsigned off = (unsigned)q * 16u;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :
+                   : "s"(dst), "v"(off), "s"(src)
+                   : "memory", "m0");
+    }
+  }
+  if (lane < rem) my[4 * nq + lane] = gr.src[4 * nq + lane];  // last 1-3 floats of a ragged tail
+}
+
+template <int N>
+__device__ __forceinline__ void lane_compute(const MapGeom& g, const LaneGroup& gr, lds_ptr my, int lane,
+                                             float (&v)[N * N]) {
+  constexpr int NN = N * N;
+  const bool act = lane < gr.nm;
+  if (gr.dense) {
+    lds_cptr p = my + (act ? lane : 0) * NN;
+    dcts::static_for<NN>([&](auto i) DCTS_LAMBDA_INLINE { v[decltype(i)::value] = p[decltype(i)::value]; });
+  } else {
+    const float* p = map_base(g, gr.m0 + (act ? lane : 0));
+    dcts::static_for<NN>([&](auto i) DCTS_LAMBDA_INLINE { v[decltype(i)::value] = p[decltype(i)::value]; });
+  }
+}
+
+template <int N>
+__device__ __forceinline__ float lane_energy(float (&v)[N * N]) {
+  dcts::static_for<N>([&](auto ic) DCTS_LAMBDA_INLINE {  // columns, in place
+    constexpr int c = decltype(ic)::value;
+    float in[N], o[N];
+    dcts::static_for<N>([&](auto ir) DCTS_LAMBDA_INLINE { in[decltype(ir)::value] = v[decltype(ir)::value * N + c]; });
+    dcts::Dct2<N>::run(in, o);
+    o[0] *= dcts::kInvSqrt2;
+    dcts::static_for<N>([&](auto ir) DCTS_LAMBDA_INLINE { v[decltype(ir)::value * N + c] = o[decltype(ir)::value]; });
+  });
+  float e = 0.f;
+  dcts::static_for<N>([&](auto ir) DCTS_LAMBDA_INLINE {  // rows
+    constexpr int r = decltype(ir)::value;
+    float in[N], o[N];
+    dcts::static_for<N>([&](auto ic) DCTS_LAMBDA_INLINE { in[decltype(ic)::value] = v[r * N + decltype(ic)::value]; });
+    dcts::Dct2<N>::run(in, o);
+    o[0] *= dcts::kInvSqrt2;
+    dcts::static_for<N>([&](auto ic) DCTS_LAMBDA_INLINE { e = fmaf(o[decltype(ic)::value], o[decltype(ic)::value], e); });
+  });
+  constexpr float sc = float(4.0 / (double(N) * double(N)));
+  return e * sc;
+}
+
+__device__ __forceinline__ LaneGroup lane_group_of(const MapGeom& g, float* out, long long grp, int nn, int item) {
+  LaneGroup gr;
+  gr.m0 = grp * 64;
+  const long long left = g.nmaps - gr.m0;
+  gr.nm = (int)(left < 64 ? left : 64);
+  gr.src = g.x + (long long)g.c_begin * g.strideC + gr.m0 * nn;
+  gr.dense = (g.contiguous && g.strideC == nn && ((reinterpret_cast<unsigned long long>(gr.src) & 15) == 0)) ? 1 : 0;
+  gr.out = out + gr.m0;
+  gr.item = item;
+  return gr;
+}
+
+// one kernel for the single-tensor and the multi-tensor entry points (count == 1 for the former)
+template <int N>
+__global__ __launch_bounds__((64 * LaneCfg<N>::WAVES)) void k_energy_lane_multi(MultiGeom mg) {
+  using Cfg = LaneCfg<N>;
+  __shared__ __attribute__((aligned(16))) float slab[Cfg::WAVES][Cfg::SLAB];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const lds_ptr my = (lds_ptr)slab[wave];
+  const long long wave_gid = (long long)blockIdx.x * Cfg::WAVES + wave;
+  const long long nwaves = (long long)gridDim.x * Cfg::WAVES;
+  int t = 0;
+  auto locate = [&](long long grp) DCTS_LAMBDA_INLINE {
+    while (t + 1 < mg.count && grp >= mg.it[t + 1].group_begin) ++t;  // wave-uniform, monotone
+    t = __builtin_amdgcn_readfirstlane(t);
+    return lane_group_of(mg.it[t].g, mg.it[t].out, grp - mg.it[t].group_begin, Cfg::NN, t);
+  };
+  if (wave_gid >= mg.total_groups) return;
+  LaneGroup cur = locate(wave_gid);
+  lane_stage<N>(cur, my, lane);
+  for (long long grp = wave_gid; grp < mg.total_groups; grp += nwaves) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the group has landed in the slab
+    float v[Cfg::NN];
+    lane_compute<N>(mg.it[cur.item].g, cur, my, lane, v);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... and is in registers: the slab is free
+    const LaneGroup done = cur;
+    if (grp + nwaves < mg.total_groups) {
+      cur = locate(grp + nwaves);
+      lane_stage<N>(cur, my, lane);
+    }
+    const float e = lane_energy<N>(v);
+    if (lane < done.nm) done.out[lane] = e;
   }
 }
 
@@ -509,8 +652,6 @@ constexpr int split_waves_per_simd() { return M <= 32 ? 4 : (M <= 48 ? 3 : 2); }
 // LDS pointers stay in address space 3 end to end: a generic pointer handed through these helpers
 // needs a flat->local cast (with a null check) at every use, which ROCm 7.2's gfx950 backend
 // mis-selects inside the fused kernel ("V_CMP_NE_U32 0, $src_shared_base": illegal instruction)
-using lds_ptr = __attribute__((address_space(3))) float*;
-using lds_cptr = const __attribute__((address_space(3))) float*;
 
 // role butterflies, in place: `base` is an LDS image [N rows][rs floats], lanes = columns
 struct NoHook {
@@ -1814,7 +1955,38 @@ int launch_codelet_multi(const MultiGeom& mg, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+constexpr bool has_lane_kernel(int n) { return n == 7 || n == 9; }
+
+template <int N>
+int launch_lane(const MultiGeom& mg, hipStream_t st) {
+  using Cfg = LaneCfg<N>;
+  static const int per_cu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_energy_lane_multi<N>, 64 * Cfg::WAVES, 0) != hipSuccess || n < 1)
+      n = 1;
+    return n;
+  }();
+  long long blocks = (mg.total_groups + Cfg::WAVES - 1) / Cfg::WAVES;
+  const long long cap = (long long)kNumCU * per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL((k_energy_lane_multi<N>), dim3((unsigned)blocks), dim3(64 * Cfg::WAVES), 0, st, mg);
+  return (int)hipGetLastError();
+}
+
+int dispatch_lane(int n, const MultiGeom& mg, hipStream_t st) {
+  switch (n) {
+    case 7:
+      return launch_lane<7>(mg, st);
+    case 9:
+      return launch_lane<9>(mg, st);
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+}
+
 int codelet_group_size(int HP) {
+  if (has_lane_kernel(HP)) return 64;
 #define DCTS_CASE(N) \
   if (HP == N) return CodeletCfg<N, N>::G;
   DCTS_CODELET_SIZES(DCTS_CASE)
@@ -1823,6 +1995,7 @@ int codelet_group_size(int HP) {
 }
 
 int dispatch_codelet_multi(int HP, int pad, const MultiGeom& mg, hipStream_t st) {
+  if (has_lane_kernel(HP) && pad == 0) return dispatch_lane(HP, mg, st);
 #define DCTS_CASE(N)                                        \
   case N:                                                   \
     if (pad) {                                              \
@@ -1880,10 +2053,22 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
   if ((algo == DCTS_ALGO_CODELET || algo == DCTS_ALGO_PREFETCH) && !codelet_ok) return DCTS_E_UNSUPPORTED;
   if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET &&
-      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED && algo != DCTS_ALGO_PIPE)
+      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED && algo != DCTS_ALGO_PIPE && algo != DCTS_ALGO_LANE)
     return DCTS_E_UNSUPPORTED;
+  if (algo == DCTS_ALGO_LANE && !(codelet_ok && !STORE && pad == 0 && has_lane_kernel((int)HP))) return DCTS_E_UNSUPPORTED;
   if (codelet_ok && algo != DCTS_ALGO_DIRECT) {
     if constexpr (!STORE) {
+      if ((algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_LANE) && pad == 0 && has_lane_kernel((int)HP)) {
+        MultiGeom mg;
+        for (int i = 0; i < kMultiItems; ++i) {
+          mg.it[i].g = g;
+          mg.it[i].out = out;
+          mg.it[i].group_begin = 0;
+        }
+        mg.total_groups = (g.nmaps + 63) / 64;
+        mg.count = 1;
+        return dispatch_lane((int)HP, mg, st);
+      }
       // the prefetching variant is opt-in: on MI355X it measured equal to the register-load
       // kernel in steady state (both at the practical HBM rate) and ~2 % slower on the bench
       if (algo == DCTS_ALGO_PREFETCH) {

@@ -61,8 +61,9 @@ enum {
                              even-edge square tiles; measured equal to ALGO_CODELET, opt-in)     */
   DCTS_ALGO_FUSED = 5,    /* single-launch split kernel, intermediate tile parked in VGPRs
                              (edges 72, 80, 112, 128, 144, 160, 224, 256)                        */
-  DCTS_ALGO_PIPE = 6      /* the fused kernel software-pipelined: pass 2 of one map interleaved
+  DCTS_ALGO_PIPE = 6,     /* the fused kernel software-pipelined: pass 2 of one map interleaved
                              with pass 1 of the next                                             */
+  DCTS_ALGO_LANE = 7      /* one lane per map, both passes in registers (7x7, 9x9)              */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */

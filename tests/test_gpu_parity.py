@@ -46,7 +46,10 @@ def test_codelet_sizes(n):
     got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_CODELET)
     check(x, got)
     auto = dpa.energy_nc(x.cuda())
-    assert torch.equal(auto, got)  # AUTO = the register-load codelet kernel
+    if n in (7, 9):  # AUTO = the lane-per-map kernel there (different summation order)
+        assert rel_err(auto.cpu(), got.cpu()) <= 1e-5
+    else:
+        assert torch.equal(auto, got)  # AUTO = the register-load codelet kernel
     if n % 2 == 0:
         # opt-in prefetching (direct-to-LDS) variant; many groups per wave exercise its loop
         check(x, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_PREFETCH))
@@ -290,7 +293,30 @@ def test_empty_and_oversize_are_errors():
         dpa.energy_nc(torch.zeros(1, 1, 224, 224).cuda(), algo=dpa.ALGO_CODELET)
 
 
-@pytest.mark.parametrize("n,pad", [(8, False), (7, False), (9, True), (14, False), (32, False), (56, False), (24, False),
+@pytest.mark.parametrize("n", [7, 9])
+def test_lane_per_map_kernel(n):
+    """One lane per map (7x7, 9x9): dense tensors stream through LDS with direct-to-LDS loads, ragged
+    tails (map counts that are not multiples of 64 or whose float count is not a multiple of 4),
+    channel slices (per-lane loads), a misaligned base, dead channels."""
+    for nmaps, seed in [(1, 1), (63, 2), (64, 3), (65, 4), (129, 5), (4099, 6), (70001, 7)]:
+        x = synth(1, nmaps, n, n, 900 + n + seed)
+        got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_LANE)
+        check(x, got)
+        assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
+        old = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_CODELET)
+        assert rel_err(got.cpu(), old.cpu()) <= 1e-5
+    x = synth(3, 40, n, n, 950 + n)
+    check(x, dpa.energy_nc(x.cuda(), c_begin=5, c_count=17, algo=dpa.ALGO_LANE), c_begin=5, c_count=17)
+    flat = torch.zeros(3 * 40 * n * n + 1)
+    flat[1:] = x.reshape(-1)
+    view = flat.cuda()[1:].view(3, 40, n, n)  # base address only 4-byte aligned
+    check(x, dpa.energy_nc(view, algo=dpa.ALGO_LANE))
+    from dct_pruning_amd._lib import DctScoreError
+    with pytest.raises(DctScoreError):
+        dpa.energy_nc(torch.zeros(1, 4, 8, 8).cuda(), algo=dpa.ALGO_LANE)
+
+
+@pytest.mark.parametrize("n,pad", [(8, False), (7, False), (9, False), (9, True), (14, False), (32, False), (56, False), (24, False),
                                    (128, False)])
 def test_energy_multi_matches_single_calls(n, pad):
     """dcts_energy_multi_f32: many tensors of one tile shape in one launch == one call per tensor
