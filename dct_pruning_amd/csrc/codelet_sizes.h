@@ -5,7 +5,7 @@
 // 3*2^k fillers.
 #pragma once
 #ifdef DCTS_DEV_FAST  // development builds: a handful of instantiations, seconds instead of minutes
-#define DCTS_CODELET_SIZES(X) X(7) X(8) X(9)
+#define DCTS_CODELET_SIZES(X) X(7) X(8) X(9) X(14) X(28) X(56)
 #define DCTS_SPLIT_TABLE(X) X(128, 32, 2) X(224, 28, 3)
 #ifndef DCTS_FUSED_TABLE
 #ifndef DCTS_DEV_M224

@@ -93,6 +93,24 @@ DCTS_HD void static_for(F&& f) {
 
 #define DCTS_LAMBDA_INLINE __attribute__((always_inline))
 
+// Two independent values carried through the same arithmetic: on gfx950 every +, -, * on this type
+// is one packed-f32 instruction (v_pk_add/mul/fma_f32, two results per issue slot). A DCT-IV of
+// even length M spawns two DCT-II of length M/2 on the rotated halves a, b: they run as ONE
+// transform on pairs (a[n], b[n]): 17 % fewer VALU instructions at 56x56 (1385 -> 1151). MEASURED
+// SLOWER on MI355X (56x56: 4.9 -> 4.4 TB/s): the packed-f32 instructions issue at half rate here
+// (the timings fit 8 cycles per v_pk_* against 4 per scalar op), so two results per instruction buy
+// nothing and the pair/unpair moves cost extra. Kept behind DCTS_PAIRS for other parts.
+typedef float f2 __attribute__((vector_size(8)));
+
+template <class T>
+struct is_pair {
+  static constexpr bool value = false;
+};
+template <>
+struct is_pair<f2> {
+  static constexpr bool value = true;
+};
+
 template <int N>
 struct Dct2;
 template <int M>
@@ -103,13 +121,39 @@ struct Dct4;
 // ---------------------------------------------------------------------------------
 template <int M>
 struct Dct4 {
-  static DCTS_HD void run(const float (&v)[M], float (&X)[M]) {
+  template <class T>
+  static DCTS_HD void run(const T (&v)[M], T (&X)[M]) {
     if constexpr (M == 1) {
       constexpr float c = float(cospi_frac(1, 4));
       X[0] = v[0] * c;
     } else if constexpr (M % 2 == 0) {
       constexpr int H = M / 2;
-      float a[H], b[H];
+#ifdef DCTS_PAIRS
+      if constexpr (!is_pair<T>::value) {
+        // a[n], b[n] as the halves of one pair; the two half-length DCT-II run as one
+        f2 ab[H];
+        static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
+          constexpr int n = decltype(i)::value;
+          constexpr float c = float(cospi_frac(2 * n + 1, 4 * M));
+          constexpr float s = float(sinpi_frac(2 * n + 1, 4 * M));
+          constexpr float sg = (n % 2 == 0) ? 1.0f : -1.0f;
+          const f2 p = {v[n], v[M - 1 - n]}, q = {v[M - 1 - n], v[n]};
+          const f2 cc = {c, sg * c}, ss = {s, -sg * s};
+          ab[n] = p * cc + q * ss;
+        });
+        f2 AB[H];
+        Dct2<H>::run(ab, AB);
+        X[0] = AB[0][0];
+        X[M - 1] = -AB[0][1];
+        static_for<H - 1>([&](auto i) DCTS_LAMBDA_INLINE {
+          constexpr int j = decltype(i)::value + 1;
+          X[2 * j] = AB[j][0] + AB[H - j][1];
+          X[2 * j - 1] = AB[j][0] - AB[H - j][1];
+        });
+        return;
+      }
+#endif
+      T a[H], b[H];
       static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
         constexpr int n = decltype(i)::value;
         constexpr float c = float(cospi_frac(2 * n + 1, 4 * M));
@@ -118,7 +162,7 @@ struct Dct4 {
         a[n] = v[n] * c + v[M - 1 - n] * s;
         b[n] = v[M - 1 - n] * (sg * c) - v[n] * (sg * s);
       });
-      float A[H], B[H];
+      T A[H], B[H];
       Dct2<H>::run(a, A);
       Dct2<H>::run(b, B);
       X[0] = A[0];
@@ -131,7 +175,7 @@ struct Dct4 {
     } else {
       static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
         constexpr int k = decltype(ik)::value;
-        float acc = 0.f;
+        T acc{};
         static_for<M>([&](auto in) DCTS_LAMBDA_INLINE {
           constexpr int n = decltype(in)::value;
           constexpr float c = float(cospi_frac((2 * n + 1) * (2 * k + 1), 4 * M));
@@ -151,18 +195,19 @@ struct Dct4 {
 // ---------------------------------------------------------------------------------
 template <int N>
 struct Dct2 {
-  static DCTS_HD void run(const float (&x)[N], float (&X)[N]) {
+  template <class T>
+  static DCTS_HD void run(const T (&x)[N], T (&X)[N]) {
     if constexpr (N == 1) {
       X[0] = x[0];
     } else if constexpr (N % 2 == 0) {
       constexpr int H = N / 2;
-      float u[H], v[H];
+      T u[H], v[H];
       static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
         constexpr int n = decltype(i)::value;
         u[n] = x[n] + x[N - 1 - n];
         v[n] = x[n] - x[N - 1 - n];
       });
-      float E[H], O[H];
+      T E[H], O[H];
       Dct2<H>::run(u, E);
       Dct4<H>::run(v, O);
       static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
@@ -172,22 +217,22 @@ struct Dct2 {
       });
     } else {
       constexpr int m = (N - 1) / 2;
-      float u[m], v[m];
+      T u[m], v[m];
       static_for<m>([&](auto i) DCTS_LAMBDA_INLINE {
         constexpr int n = decltype(i)::value;
         u[n] = x[n] + x[N - 1 - n];
         v[n] = x[n] - x[N - 1 - n];
       });
-      const float mid = x[m];
+      const T mid = x[m];
       static_for<N>([&](auto ik) DCTS_LAMBDA_INLINE {
         constexpr int k = decltype(ik)::value;
         if constexpr (k == 0) {
-          float acc = mid;
+          T acc = mid;
           static_for<m>([&](auto in) DCTS_LAMBDA_INLINE { acc += u[decltype(in)::value]; });
           X[0] = acc;
         } else if constexpr (k % 2 == 0) {
           // middle sample: cos(pi N k / (2N)) = cos(pi k / 2) = (-1)^(k/2)
-          float acc = ((k / 2) % 2 == 0) ? mid : -mid;
+          T acc = ((k / 2) % 2 == 0) ? mid : -mid;
           static_for<m>([&](auto in) DCTS_LAMBDA_INLINE {
             constexpr int n = decltype(in)::value;
             constexpr float c = float(cospi_frac((2 * n + 1) * k, 2 * N));
@@ -195,7 +240,7 @@ struct Dct2 {
           });
           X[k] = acc;
         } else {
-          float acc = 0.f;
+          T acc{};
           static_for<m>([&](auto in) DCTS_LAMBDA_INLINE {
             constexpr int n = decltype(in)::value;
             constexpr float c = float(cospi_frac((2 * n + 1) * k, 2 * N));

@@ -83,18 +83,30 @@ __device__ __forceinline__ void codelet_group(const MapGeom& g, float* __restric
   // ---- pass 1: column DCT-II of length HP, lane = column -------------------------
   const long long m1 = grp * G + g1;
   float xr[HP];
-  const bool ld = act1 && m1 < g.nmaps && c >= PAD;
-  if (ld) {
-    const float* p = map_base(g, m1) + (c - PAD);
+  if constexpr (PAD == 0) {
+    // No branch and no zero fill: lanes without a map (beyond G*WP, or past the last map of a ragged
+    // group) load some valid map instead and their results are never stored. The kernel is
+    // VALU-issue-bound; the HP v_mov 0 per iteration of the zero fill were 4-6 % of its instructions.
+    const bool has = act1 && m1 < g.nmaps;
+    const float* p = map_base(g, has ? m1 : g.nmaps - 1) + (has ? c : 0);
     dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(i)::value;
-      if constexpr (r < PAD)
-        xr[r] = 0.f;
-      else
-        xr[r] = p[(r - PAD) * W];
+      xr[r] = p[r * W];
     });
   } else {
-    dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE { xr[decltype(i)::value] = 0.f; });
+    const bool ld = act1 && m1 < g.nmaps && c >= PAD;
+    if (ld) {
+      const float* p = map_base(g, m1) + (c - PAD);
+      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int r = decltype(i)::value;
+        if constexpr (r < PAD)
+          xr[r] = 0.f;
+        else
+          xr[r] = p[(r - PAD) * W];
+      });
+    } else {
+      dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE { xr[decltype(i)::value] = 0.f; });
+    }
   }
   float y[HP];
   dcts::Dct2<HP>::run(xr, y);
