@@ -325,13 +325,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
-    # sanity on the result the timed region produced: Parseval against the inputs (device-side)
+    # sanity on the result the timed region produced: Parseval against the inputs (device-side),
+    # and the dead channels of the synthetic tensors (c % 8 == 5) must come out as exactly +0.0
     i0, b0 = bound[0]
     ref = (b0.x.double() ** 2).sum(dim=(-2, -1)).mean(0)
     got = gathered[rank, off[i0]:off[i0] + b0.fr.numel()].double()
     rel = ((got - ref).abs() / ref.clamp_min(1e-30))[ref > 0].max().item()
     if not rel <= 1e-4:
         sys.exit("bench sanity check failed: rel err %g" % rel)
+    dead_bad = 0
+    for i, b in bound:
+        fr = gathered[rank, off[i]:off[i] + b.fr.numel()]
+        dead = (b.x[0].reshape(b.x.shape[1], -1).abs().amax(dim=1) == 0) & (b.x.abs().amax(dim=(0, 2, 3)) == 0)
+        dead_bad += int(((fr[dead] != 0) | torch.signbit(fr[dead])).sum().item())
+    if dead_bad:
+        sys.exit("bench sanity check failed: %d dead channels are not exactly +0.0" % dead_bad)
+
+    # the collective on its own (reported separately), outside the timed region
+    gather_ms = None
+    if world > 1:
+        barrier()
+        tg = time.perf_counter()
+        gather()
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
 
     # events come in (start, stop) pairs around each contiguous group of dominant-kernel launches
     dom_ms = sum(events[i].elapsed_time(events[i + 1]) for i in range(0, len(events), 2))
@@ -371,8 +388,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": n_launch, "avg_launch_us": dom_ms / n_launch * 1e3,
                          "alg_bytes_per_launch": dom_bytes / n_launch},
-            "parity_check_rel_err": rel,
+            "parity_check_rel_err": rel, "dead_channels_not_plus_zero": dead_bad,
         }
+        if gather_ms is not None:
+            res["all_gather_ms"] = gather_ms  # flat buffer fill + one all_gather_into_tensor + barriers
         if not args.no_headline and world == 1:
             res["headline"] = headline(lib, dev, stream_ptr, ws_fn)
         if not args.no_cpu_baseline and world == 1:

@@ -6,7 +6,9 @@
 #pragma once
 #ifdef DCTS_DEV_FAST  // development builds: a handful of instantiations, seconds instead of minutes
 #define DCTS_CODELET_SIZES(X) X(7) X(8) X(9) X(14) X(28) X(56)
+#ifndef DCTS_SPLIT_TABLE
 #define DCTS_SPLIT_TABLE(X) X(128, 32, 2) X(224, 28, 3)
+#endif
 #ifndef DCTS_FUSED_TABLE
 #ifndef DCTS_DEV_M224
 #define DCTS_DEV_M224 14
