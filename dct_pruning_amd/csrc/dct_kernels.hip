@@ -29,6 +29,24 @@
 #include "codelet_sizes.h"
 #include "dct_codelets.hpp"
 
+// The file is compiled five times in parallel (Makefile: -DDCTS_TU=1..5), each translation unit
+// instantiating one kernel family; DCTS_TU=0 (default) builds everything in one unit. Only the
+// dispatchers that instantiate kernels cross units: they are declared here with the geometry
+// structs passed as opaque pointers (the structs live in the anonymous namespace of every unit).
+#ifndef DCTS_TU
+#define DCTS_TU 0
+#endif
+#define DCTS_PART(n) (DCTS_TU == 0 || DCTS_TU == (n))  // 1 codelet+lane, 2 two-launch split, 3 fused, 4 pipelined, 5 rest + C ABI
+namespace dctsi {
+int dispatch_codelet(int store, int HP, int WP, int pad, const void* geom, float* out, hipStream_t st);
+int dispatch_codelet_dma(int N, const void* geom, float* out, hipStream_t st);
+int dispatch_codelet_multi(int HP, int pad, const void* multi_geom, hipStream_t st);
+int dispatch_lane(int n, const void* multi_geom, hipStream_t st);
+int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStream_t st);
+int dispatch_fused(int N, const void* geom, float* out, hipStream_t st);
+int dispatch_pipe(int N, const void* geom, float* out, hipStream_t st);
+}  // namespace dctsi
+
 namespace {
 
 // LDS pointers stay in address space 3 end to end (see the split family for why)
@@ -1748,7 +1766,12 @@ bool dma_ok(int HP, int WP, int pad, const MapGeom& g) {
   return (reinterpret_cast<uintptr_t>(g.x + (long long)g.c_begin * g.strideC) & 15) == 0;
 }
 
-int dispatch_codelet_dma(int N, const MapGeom& g, float* out, hipStream_t st) {
+}  // namespace
+#if DCTS_PART(1)
+namespace dctsi {
+int dispatch_codelet_dma(int N, const void* geom, float* out, hipStream_t st) {
+  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+
 #define DCTS_CASE(N_) \
   case N_:            \
     return launch_codelet_dma<N_>(g, out, st);
@@ -1759,9 +1782,15 @@ int dispatch_codelet_dma(int N, const MapGeom& g, float* out, hipStream_t st) {
   }
 #undef DCTS_CASE
 }
+}  // namespace dctsi
+#endif
+namespace {
+inline int dispatch_codelet_dma(int N, const MapGeom& g, float* out, hipStream_t st) {
+  return dctsi::dispatch_codelet_dma(N, &g, out, st);
+}
 
 template <bool STORE>
-int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipStream_t st) {
+int dispatch_codelet_impl(int HP, int WP, int pad, const MapGeom& g, float* out, hipStream_t st) {
   if (HP != WP) return DCTS_E_UNSUPPORTED;
 #define DCTS_CASE(N)                                                          \
   case N:                                                                     \
@@ -1778,6 +1807,20 @@ int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipS
       return DCTS_E_UNSUPPORTED;
   }
 #undef DCTS_CASE
+}
+}  // namespace
+#if DCTS_PART(1)
+namespace dctsi {
+int dispatch_codelet(int store, int HP, int WP, int pad, const void* geom, float* out, hipStream_t st) {
+  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+  return store ? dispatch_codelet_impl<true>(HP, WP, pad, g, out, st) : dispatch_codelet_impl<false>(HP, WP, pad, g, out, st);
+}
+}  // namespace dctsi
+#endif
+namespace {
+template <bool STORE>
+inline int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* out, hipStream_t st) {
+  return dctsi::dispatch_codelet(STORE ? 1 : 0, HP, WP, pad, &g, out, st);
 }
 
 // tile edges served by the split family: X(N, M, L) with N = M << L. L = 3 (eight M-point roles)
@@ -1889,7 +1932,12 @@ int launch_fused(const MapGeom& g, float* out, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
+}  // namespace
+#if DCTS_PART(3)
+namespace dctsi {
+int dispatch_fused(int N, const void* geom, float* out, hipStream_t st) {
+  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+
 #define DCTS_CASE(N_, M_, L_) \
   case N_:                    \
     return launch_fused<M_, L_>(g, out, st);
@@ -1899,6 +1947,12 @@ int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
       return DCTS_E_UNSUPPORTED;
   }
 #undef DCTS_CASE
+}
+}  // namespace dctsi
+#endif
+namespace {
+inline int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
+  return dctsi::dispatch_fused(N, &g, out, st);
 }
 
 // pipelined variant X(N, M, L)
@@ -1931,7 +1985,12 @@ int launch_pipe(const MapGeom& g, float* out, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int dispatch_pipe(int N, const MapGeom& g, float* out, hipStream_t st) {
+}  // namespace
+#if DCTS_PART(4)
+namespace dctsi {
+int dispatch_pipe(int N, const void* geom, float* out, hipStream_t st) {
+  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+
 #define DCTS_CASE(N_, M_, L_) \
   case N_:                    \
     return launch_pipe<M_, L_>(g, out, st);
@@ -1942,8 +2001,19 @@ int dispatch_pipe(int N, const MapGeom& g, float* out, hipStream_t st) {
   }
 #undef DCTS_CASE
 }
+}  // namespace dctsi
+#endif
+namespace {
+inline int dispatch_pipe(int N, const MapGeom& g, float* out, hipStream_t st) {
+  return dctsi::dispatch_pipe(N, &g, out, st);
+}
 
-int dispatch_split(int N, const MapGeom& g, float* out, void* workspace, hipStream_t st) {
+}  // namespace
+#if DCTS_PART(2)
+namespace dctsi {
+int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStream_t st) {
+  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+
 #define DCTS_CASE(N_, M_, L_) \
   case N_:                    \
     return launch_split<M_, L_>(g, out, workspace, st);
@@ -1953,6 +2023,12 @@ int dispatch_split(int N, const MapGeom& g, float* out, void* workspace, hipStre
       return DCTS_E_UNSUPPORTED;
   }
 #undef DCTS_CASE
+}
+}  // namespace dctsi
+#endif
+namespace {
+inline int dispatch_split(int N, const MapGeom& g, float* out, void* workspace, hipStream_t st) {
+  return dctsi::dispatch_split(N, &g, out, workspace, st);
 }
 
 template <int HP, int WP, int PAD>
@@ -1986,7 +2062,12 @@ int launch_lane(const MultiGeom& mg, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
-int dispatch_lane(int n, const MultiGeom& mg, hipStream_t st) {
+}  // namespace
+#if DCTS_PART(1)
+namespace dctsi {
+int dispatch_lane(int n, const void* multi_geom, hipStream_t st) {
+  const MultiGeom& mg = *static_cast<const MultiGeom*>(multi_geom);
+
   switch (n) {
     case 7:
       return launch_lane<7>(mg, st);
@@ -1995,6 +2076,12 @@ int dispatch_lane(int n, const MultiGeom& mg, hipStream_t st) {
     default:
       return DCTS_E_UNSUPPORTED;
   }
+}
+}  // namespace dctsi
+#endif
+namespace {
+inline int dispatch_lane(int n, const MultiGeom& mg, hipStream_t st) {
+  return dctsi::dispatch_lane(n, &mg, st);
 }
 
 int codelet_group_size(int HP) {
@@ -2006,8 +2093,13 @@ int codelet_group_size(int HP) {
   return 0;
 }
 
-int dispatch_codelet_multi(int HP, int pad, const MultiGeom& mg, hipStream_t st) {
-  if (has_lane_kernel(HP) && pad == 0) return dispatch_lane(HP, mg, st);
+}  // namespace
+#if DCTS_PART(1)
+namespace dctsi {
+int dispatch_codelet_multi(int HP, int pad, const void* multi_geom, hipStream_t st) {
+  const MultiGeom& mg = *static_cast<const MultiGeom*>(multi_geom);
+
+  if (has_lane_kernel(HP) && pad == 0) return dctsi::dispatch_lane(HP, &mg, st);
 #define DCTS_CASE(N)                                        \
   case N:                                                   \
     if (pad) {                                              \
@@ -2023,6 +2115,12 @@ int dispatch_codelet_multi(int HP, int pad, const MultiGeom& mg, hipStream_t st)
       return DCTS_E_UNSUPPORTED;
   }
 #undef DCTS_CASE
+}
+}  // namespace dctsi
+#endif
+namespace {
+inline int dispatch_codelet_multi(int HP, int pad, const MultiGeom& mg, hipStream_t st) {
+  return dctsi::dispatch_codelet_multi(HP, pad, &mg, st);
 }
 
 bool has_codelet(long long HP, long long WP) {
@@ -2128,6 +2226,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
 
 }  // namespace
 
+#if DCTS_PART(5)
 extern "C" {
 
 int dcts_version(void) { return DCTS_ABI_VERSION; }
@@ -2311,3 +2410,4 @@ int dcts_debug_stream_read_f32(const float* x, int64_t n, float* sink, void* str
 }
 
 }  // extern "C"
+#endif  // DCTS_PART(5)

@@ -4,7 +4,7 @@
 set -e
 edge=${1:-224}; nmaps=${2:-4096}
 mkdir -p gpurun_out/stamps
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -fno-slp-vectorize -DDCTS_FUSED_STAMPS \
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wno-inline-asm -fno-slp-vectorize -DDCTS_FUSED_STAMPS \
   -o gpurun_out/stamps/libdctscore_stamps.so dct_pruning_amd/csrc/dct_kernels.hip
 python3 - "$edge" "$nmaps" <<'PY'
 import ctypes, sys, torch

@@ -6,7 +6,7 @@ set -e
 edge=${1:-224}; nmaps=${2:-4096}
 if [ ! -f build_dev/libstamps.so ]; then
   mkdir -p build_dev
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -fno-slp-vectorize -DDCTS_DEV_FAST \
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wno-inline-asm -fno-slp-vectorize -DDCTS_DEV_FAST \
     -DDCTS_FUSED_STAMPS -o build_dev/libstamps.so dct_pruning_amd/csrc/dct_kernels.hip
 fi
 python3 - "$edge" "$nmaps" <<'PY'
