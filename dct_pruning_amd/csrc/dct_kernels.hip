@@ -1007,20 +1007,7 @@ struct FusedStage {
   static constexpr int NQUADS = N * SW / 4;
   static constexpr int PIECES = (NQUADS + THREADS - 1) / THREADS;
   static_assert(SW == 64, "piece addressing assumes 16 quads per row");
-  static __device__ __forceinline__ void piece(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
-                                               int wave, int it) {
-    const int qbase = it * THREADS + wave * 64;  // wave-uniform
-    const int q = qbase + lane;
-    const int row = q >> 4, col = (q & 15) << 2;
-    if (q < NQUADS && strip * SW + col < N) {
-      // uniform base + 32-bit lane offset: the saddr form needs one address VGPR instead of two
-      const float* base = in_b + strip * SW;
-      const unsigned off = (unsigned)(row * N + col);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                       (__attribute__((address_space(3))) void*)(buf + 4 * qbase), 16, 0, 0);
-    }
-  }
-  // The same load as a raw instruction. The compiler tracks direct-to-LDS loads it knows about and
+  // One direct-to-LDS load, issued as a raw instruction. The compiler tracks direct-to-LDS loads it knows about and
   // puts s_waitcnt vmcnt(0) in front of the next LDS access that may alias the destination; its
   // alias information does not survive this kernel's pointer arithmetic, so EVERY following
   // ds_read/ds_write waited for the prefetch to land (one memory round trip per instalment). The
@@ -1039,11 +1026,6 @@ struct FusedStage {
                    : "s"(dst), "v"(off), "s"(base)
                    : "memory", "m0");
     }
-  }
-  static __device__ __forceinline__ void all(const float* __restrict__ in_b, int strip, lds_ptr buf, int lane,
-                                             int wave) {
-#pragma unroll
-    for (int it = 0; it < PIECES; ++it) piece(in_b, strip, buf, lane, wave, it);
   }
 };
 
