@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Soak for races: the pipelined and lane-per-map kernels on random map counts, twice each (must be
+bit-identical) and against sum(x^2) (Parseval, 1e-5). usage: tools/soak.py [iterations]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dct_pruning_amd as dpa  # noqa: E402
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(7)
+bad = 0
+for it in range(iters):
+    edge, algo, hi = [(224, dpa.ALGO_PIPE, 1500), (128, dpa.ALGO_PIPE, 4000), (7, dpa.ALGO_LANE, 300000),
+                      (9, dpa.ALGO_LANE, 200000), (224, dpa.ALGO_FUSED, 1500), (256, dpa.ALGO_FUSED, 1200)][it % 6]
+    nmaps = int(rng.integers(1, hi))
+    x = torch.relu(torch.randn(1, nmaps, edge, edge, device="cuda"))
+    a = dpa.energy_nc(x, algo=algo)
+    b = dpa.energy_nc(x, algo=algo)
+    ref = (x.double() ** 2).sum(dim=(-2, -1))
+    rel = ((a.double() - ref).abs() / ref.clamp_min(1e-30)).max().item()
+    if not torch.equal(a, b) or not rel <= 1e-5:
+        bad += 1
+        print("MISMATCH edge %d algo %d nmaps %d: equal=%s rel=%g" % (edge, algo, nmaps, torch.equal(a, b), rel), flush=True)
+    if it % 50 == 0:
+        print("iter", it, "ok so far, bad =", bad, flush=True)
+print("soak done: %d iterations, %d bad" % (iters, bad))
+sys.exit(1 if bad else 0)
