@@ -224,6 +224,10 @@ def main():
         x = synth(N, u.c_hi - u.c_lo, p.H, p.W, 20260104 + 1000 * CFG_ID + 64 * u.layer + (u.c_lo % 61), dev)
         bound.append((i, BoundUnit(lib, x, scored[u.layer][2], stream_ptr, ws_fn(N, u.c_hi - u.c_lo, p.H, p.W))))
     maps_per_step = N * sum(chans)
+    per_edge = {}
+    for p, ch in zip(points, chans):
+        per_edge[p.H] = per_edge.get(p.H, 0) + ch
+    shape_summary = ", ".join("%dx%d x%d" % (e, e, per_edge[e]) for e in sorted(per_edge, reverse=True))
 
     # dominant kernel: the one owning the most algorithmic bytes on this rank
     by_edge = {}
@@ -375,8 +379,8 @@ def main():
             "unit": "Mmaps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s hooked feature maps (49 tensors, %d maps/sample: 56x56 x1344, 28x28 x3200, "
-                                   "14x14 x9472, 7x7 x8704), batch %d, limit=steps" % (args.net, sum(chans), N),
+            "config": {"workload": "%s hooked feature maps (%d tensors, %d maps/sample: %s), batch %d, limit=steps"
+                                   % (args.net, len(points), sum(chans), shape_summary, N),
                        "global_batch": N, "sharding": "layer-sharded (LPT on bytes), 1 all-gather" if world > 1 else "none",
                        "launch_mode": "per-tensor" if args.per_tensor else "one launch per tile shape",
                        "units_rank0": len(bound), "load_imbalance": (max(load) / (sum(load) / world)) if world > 1 else 1.0},

@@ -36,6 +36,9 @@
 #ifndef DCTS_TU
 #define DCTS_TU 0
 #endif
+#ifndef DCTS_FUSED2_AUTO
+#define DCTS_FUSED2_AUTO 1  // AUTO uses the two-roles-per-wave fused kernel where it exists (288: 30.7 % vs 18.2 %)
+#endif
 #define DCTS_PART(n) (DCTS_TU == 0 || DCTS_TU == (n))  // 1 codelet+lane, 2 two-launch split, 3 fused, 4 pipelined, 5 rest + C ABI
 namespace dctsi {
 int dispatch_codelet(int store, int HP, int WP, int pad, const void* geom, float* out, hipStream_t st);
@@ -44,6 +47,7 @@ int dispatch_codelet_multi(int HP, int pad, const void* multi_geom, hipStream_t 
 int dispatch_lane(int n, const void* multi_geom, hipStream_t st);
 int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStream_t st);
 int dispatch_fused(int N, const void* geom, float* out, hipStream_t st);
+int dispatch_fused2(int N, const void* geom, float* out, hipStream_t st);
 int dispatch_pipe(int N, const void* geom, float* out, hipStream_t st);
 }  // namespace dctsi
 
@@ -742,14 +746,14 @@ __device__ __forceinline__ void split_butterflies_pk(lds_ptr base, int rs, bool 
   }
 }
 
-template <int M, int L, class Hook = NoHook>
+template <int M, int L, class Hook = NoHook, int NW = (1 << L)>
 __device__ __forceinline__ void split_butterflies_1(lds_ptr base, int rs, bool lane_ok, int lane, int wave,
                                                     Hook hook = Hook{}) {
-  constexpr int S = 1 << L;
+  constexpr int S = 1 << L;  // samples of one item; NW waves share the M items (NW < S: two roles per wave)
   constexpr RolePlan<L> plan{};
   const RotTable<M, L>& tab = kRotTable<M, L>;
   lds_ptr colp = base + (lane_ok ? lane : 0);
-  for (int p = wave; p < M; p += S) {
+  for (int p = wave; p < M; p += NW) {
     const float sp = (p & 1) ? -1.f : 1.f;  // (-1)^p
     float y[S];
     dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
@@ -786,13 +790,13 @@ __device__ __forceinline__ void split_butterflies_1(lds_ptr base, int rs, bool l
 // 2^L live samples. Measured: +3..5 % in the two-launch pass kernel (288, 320), -2..8 % in the
 // eight-wave fused kernels (too few waves left to hide LDS latency), spills in the sixteen-wave
 // ones. So only k_pass1d asks for it.
-template <int M, int L, class Hook = NoHook, bool PACK = false>
+template <int M, int L, class Hook = NoHook, bool PACK = false, int NW = (1 << L)>
 __device__ __forceinline__ void split_butterflies(lds_ptr base, int rs, bool lane_ok, int lane, int wave,
                                                   Hook hook = Hook{}) {
   if constexpr (PACK)
     split_butterflies_pk<M, L>(base, rs, lane_ok, lane, wave, hook);
   else
-    split_butterflies_1<M, L>(base, rs, lane_ok, lane, wave, hook);
+    split_butterflies_1<M, L, Hook, NW>(base, rs, lane_ok, lane, wave, hook);
 }
 
 // role r's M-point transform of one column of the butterflied image: gathers the role's input
@@ -1000,10 +1004,9 @@ struct FusedCfg {
 
 // one direct-to-LDS instruction (64 lanes x 16 B) of a strip's staging: piece `it` of PIECES.
 // lane q = it*THREADS + wave*64 + lane covers row q/16, columns 4*(q%16).. of the 64-wide strip
-template <int M, int L>
+template <int M, int L, int NW = (1 << L)>
 struct FusedStage {
-  using Cfg = FusedCfg<M, L>;
-  static constexpr int N = Cfg::N, SW = Cfg::SW, THREADS = 64 << L;
+  static constexpr int N = M << L, SW = 64, THREADS = 64 * NW;
   static constexpr int NQUADS = N * SW / 4;
   static constexpr int PIECES = (NQUADS + THREADS - 1) / THREADS;
   static_assert(SW == 64, "piece addressing assumes 16 quads per row");
@@ -1217,6 +1220,169 @@ __global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_s
   __shared__ float partials[2 * Cfg::S];
   fused_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63,
                        std::make_integer_sequence<int, Cfg::S>{});
+}
+
+// ---------------------------------------------------------------------------------------
+// fused kernel with two roles per wave: 288 = 18 x 16 roles on eight waves
+// ---------------------------------------------------------------------------------------
+// A 288 x 288 tile (81 K floats) fits the register file of a CU (128 K floats) but not next to the
+// codelet working set at 16 waves x 128 VGPRs (5 strips x 18 parked + ~60). Eight waves own 256
+// VGPRs each: wave w runs roles 2w and 2w+1 one after the other (2 x 5 x 18 = 180 parked values),
+// the butterfly items are shared by the eight waves, the pass-2 dump is the balanced one (KPR
+// coefficients of every role per round). Otherwise the fused kernel above: double-buffered
+// direct-to-LDS staging, LDS-only barriers, deferred workgroup sum. One launch, HBM traffic = the
+// input once, instead of the 3x of the two-launch path.
+template <int M, int L>
+struct Fused2Cfg {
+  static constexpr int N = M << L, S = 1 << L, NW = S / 2, SW = 64;
+  static constexpr int STRIPS = (N + SW - 1) / SW;
+  static constexpr int KPR = 64 / S;
+  static constexpr int ROUNDS = (M + KPR - 1) / KPR;
+  static constexpr int RW = 65;
+  static constexpr int BUF = N * RW;  // >= N * SW
+  static_assert(S >= 2 && S <= 16 && N % 4 == 0, "shape");
+};
+
+template <int M, int L, int W>
+__device__ __forceinline__ void fused2_body(const float* __restrict__ x, long long map_stride, long long nmaps,
+                                            float* __restrict__ out, lds_ptr buf0, lds_ptr buf1, lds_ptr partials,
+                                            int lane_in) {
+  using Cfg = Fused2Cfg<M, L>;
+  using Stage = FusedStage<M, L, Cfg::NW>;
+  constexpr int N = Cfg::N, NW = Cfg::NW, SW = Cfg::SW, STRIPS = Cfg::STRIPS, KPR = Cfg::KPR,
+                ROUNDS = Cfg::ROUNDS, RW = Cfg::RW;
+  constexpr int R0 = 2 * W, R1 = 2 * W + 1;
+  int cur = 0, pslot = 0, pending_slot = 0;
+  long long pending_m = -1;
+  long long m = blockIdx.x;
+  auto finish = [&](int slot, long long mm) DCTS_LAMBDA_INLINE {
+    if (W == 0 && lane_in == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) t += partials[slot * NW + i];
+      constexpr float sc = float(4.0 / (double(N) * double(N)));
+      out[mm] = t * sc;
+    }
+  };
+  if (m < nmaps) {
+#pragma unroll
+    for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(x + m * map_stride, 0, buf0, lane_in, W, it);
+  }
+  for (; m < nmaps; m += gridDim.x) {
+    const float* in_b = x + m * map_stride;
+    float parked[2][STRIPS][M];
+    // ---- pass 1: H axis, strip by strip -------------------------------------------------
+    dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
+      constexpr int s = decltype(is)::value;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this strip has landed
+      lds_barrier();                                     // ... for everyone; the other buffer is free
+      if constexpr (s == 0) {
+        if (pending_m >= 0) {
+          finish(pending_slot, pending_m);
+          pending_m = -1;
+        }
+      }
+      const lds_ptr buf = cur ? buf1 : buf0;
+      const lds_ptr nxt = cur ? buf0 : buf1;
+      const bool more = (s + 1 < STRIPS) || (m + gridDim.x < nmaps);
+      const float* nsrc = (s + 1 < STRIPS) ? in_b : x + (m + gridDim.x) * map_stride;
+      constexpr int nstrip = (s + 1 < STRIPS) ? s + 1 : 0;
+      if (more) {
+#pragma unroll
+        for (int it = 0; it < Stage::PIECES; it += 2) Stage::piece_raw(nsrc, nstrip, nxt, launder(lane_in), W, it);
+      }
+      int lane = launder(lane_in);
+      const bool act = s * SW + lane < N;
+      split_butterflies<M, L, NoHook, false, NW>(buf, SW, act, lane, W);
+      if (more) {
+#pragma unroll
+        for (int it = 1; it < Stage::PIECES; it += 2) Stage::piece_raw(nsrc, nstrip, nxt, launder(lane_in), W, it);
+      }
+      lds_barrier();
+      lane = launder(lane_in);
+      dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
+        constexpr int i = decltype(ii)::value;
+        const int ln = launder(lane_in);
+        float o[M];
+        split_role_transform<M, L, 2 * W + i>(buf + (act ? ln : 0), SW, o);
+        dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+          constexpr int k = decltype(ik)::value;
+          asm volatile("" : "+v"(o[k]));  // pin the codelet here (LLVM would sink it to the dump)
+          parked[i][s][k] = o[k];
+        });
+      });
+      cur ^= 1;
+    });
+    // ---- pass 2: W axis, KPR coefficients of every role per round ---------------------------
+    const lds_ptr blk = cur ? buf0 : buf1;  // the last strip's buffer; the other one is receiving
+    float e = 0.f;
+    dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
+      constexpr int r = decltype(ir)::value;
+      lds_barrier();  // previous readers of blk are done
+      int lane = launder(lane_in);
+      dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
+        constexpr int i = decltype(ii)::value;
+        dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
+          constexpr int s = decltype(is)::value;
+          const int line = s * SW + lane;
+          const int off = (line < N ? line : 0) * RW + (2 * W + i) * KPR;
+          dcts::static_for<KPR>([&](auto ic) DCTS_LAMBDA_INLINE {
+            constexpr int c = decltype(ic)::value;
+            if constexpr (r * KPR + c < M) {
+              if (line < N) blk[off + c] = parked[i][s][r * KPR + c];
+            } else {
+              if (line < N) blk[off + c] = 0.f;  // padding column: contributes exactly zero energy
+            }
+          });
+        });
+      });
+      lds_barrier();
+      lane = launder(lane_in);
+      split_butterflies<M, L, NoHook, false, NW>(blk, RW, true, lane, W);
+      lds_barrier();
+      dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
+        constexpr int i = decltype(ii)::value;
+        const int ln = launder(lane_in);
+        float o[M];
+        split_role_transform<M, L, 2 * W + i>(blk + ln, RW, o);
+        float er = 0.f;
+        dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+          constexpr int k = decltype(ik)::value;
+          er = fmaf(o[k], o[k], er);
+        });
+        asm volatile("" : "+v"(er));
+        e += er;
+      });
+    });
+    e = wave_sum_dpp(e);
+    if (lane_in == 0) partials[pslot * NW + W] = e;
+    pending_m = m;
+    pending_slot = pslot;
+    pslot ^= 1;
+  }
+  if (pending_m >= 0) {
+    lds_barrier();
+    finish(pending_slot, pending_m);
+  }
+}
+
+template <int M, int L, int... Wv>
+__device__ __forceinline__ void fused2_dispatch(int wave, const float* x, long long map_stride, long long nmaps,
+                                                float* out, lds_ptr buf0, lds_ptr buf1, lds_ptr partials, int lane,
+                                                std::integer_sequence<int, Wv...>) {
+  ((wave == Wv ? fused2_body<M, L, Wv>(x, map_stride, nmaps, out, buf0, buf1, partials, lane) : (void)0), ...);
+}
+
+template <int M, int L>
+__global__ __launch_bounds__((64 * Fused2Cfg<M, L>::NW), 2) void k_split_fused2(const float* __restrict__ x,
+                                                                                 long long map_stride, long long nmaps,
+                                                                                 float* __restrict__ out) {
+  using Cfg = Fused2Cfg<M, L>;
+  __shared__ __attribute__((aligned(16))) float buf0[Cfg::BUF];
+  __shared__ __attribute__((aligned(16))) float buf1[Cfg::BUF];
+  __shared__ float partials[2 * Cfg::NW];
+  fused2_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)partials,
+                        threadIdx.x & 63, std::make_integer_sequence<int, Cfg::NW>{});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1937,6 +2103,48 @@ inline int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
   return dctsi::dispatch_fused(N, &g, out, st);
 }
 
+// two roles per wave X(N, M, L): tiles the 16-wave kernels cannot park. (320 = 20 x 16 fits the
+// registers, 221 VGPRs, but its two LDS buffers need 166 464 bytes: 2.6 KB over the 160 KiB.)
+#ifndef DCTS_FUSED2_TABLE
+#define DCTS_FUSED2_TABLE(X) X(288, 18, 4)
+#endif
+
+bool has_fused2(long long N) {
+#define DCTS_CASE(N_, M_, L_) \
+  if (N == N_) return true;
+  DCTS_FUSED2_TABLE(DCTS_CASE)
+#undef DCTS_CASE
+  return false;
+}
+
+template <int M, int L>
+int launch_fused2(const MapGeom& g, float* out, hipStream_t st) {
+  const float* x0 = g.x + (long long)g.c_begin * g.strideC;
+  const long long cap = kNumCU;  // LDS: one workgroup per CU
+  const long long grid = g.nmaps < cap ? g.nmaps : cap;
+  hipLaunchKernelGGL((k_split_fused2<M, L>), dim3((unsigned)grid), dim3(64 * Fused2Cfg<M, L>::NW), 0, st, x0, g.strideC,
+                     g.nmaps, out);
+  return (int)hipGetLastError();
+}
+}  // namespace
+#if DCTS_PART(3)
+namespace dctsi {
+int dispatch_fused2(int N, const void* geom, float* out, hipStream_t st) {
+  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+#define DCTS_CASE(N_, M_, L_) \
+  case N_:                    \
+    return launch_fused2<M_, L_>(g, out, st);
+  switch (N) {
+    DCTS_FUSED2_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+}  // namespace dctsi
+#endif
+namespace {
+
 // pipelined variant X(N, M, L)
 #ifndef DCTS_PIPE_TABLE
 // (measured against the fused kernel, % of 8 TB/s: 128: 49.2 vs 46.9, 224: 36.8 vs 33.1; it loses
@@ -2176,8 +2384,11 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     const bool split_ok = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous &&
                           strideC == H * W;
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
-    const bool fused_ok = split_ok && has_fused(HP) &&
-                          (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
+    const bool aligned16 = (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
+    const bool fused2_ok = split_ok && has_fused2(HP) && aligned16;
+    if (fused2_ok && (algo == DCTS_ALGO_FUSED || (algo == DCTS_ALGO_AUTO && DCTS_FUSED2_AUTO)))
+      return dctsi::dispatch_fused2((int)HP, &g, out, st);
+    const bool fused_ok = split_ok && has_fused(HP) && aligned16;
     if (algo == DCTS_ALGO_FUSED && !fused_ok) return DCTS_E_UNSUPPORTED;
     const bool pipe_ok = fused_ok && has_pipe(HP);
     if (algo == DCTS_ALGO_PIPE) return pipe_ok ? dispatch_pipe((int)HP, g, out, st) : DCTS_E_UNSUPPORTED;
