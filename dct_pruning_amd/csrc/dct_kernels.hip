@@ -37,7 +37,7 @@
 #define DCTS_TU 0
 #endif
 #ifndef DCTS_FUSED2_AUTO
-#define DCTS_FUSED2_AUTO 1  // AUTO uses the two-roles-per-wave fused kernel where it exists (288: 30.7 % vs 18.2 %)
+#define DCTS_FUSED2_AUTO 1  // AUTO uses the two-roles-per-wave fused kernel where it exists (288: 31 % vs 18 %, 320: 31 % vs 17 % of the HBM peak)
 #endif
 #define DCTS_PART(n) (DCTS_TU == 0 || DCTS_TU == (n))  // 1 codelet+lane, 2 two-launch split, 3 fused, 4 pipelined, 5 rest + C ABI
 namespace dctsi {
@@ -1236,11 +1236,21 @@ template <int M, int L>
 struct Fused2Cfg {
   static constexpr int N = M << L, S = 1 << L, NW = S / 2, SW = 64;
   static constexpr int STRIPS = (N + SW - 1) / SW;
-  static constexpr int KPR = 64 / S;
+  // Two LDS buffers of max(strip, pass-2 image) floats. With all 64 columns per round the image
+  // (N x 65) is the larger one; where two of those exceed the 160 KiB (320: 166 KB) a round takes
+  // 48 columns (KPR = 3 per role, image N x 49) and the workgroup partials move into the slack behind
+  // the image, which costs the deferred workgroup sum (one more barrier per map).
+  static constexpr int LDS_FLOATS = 160 * 1024 / 4;
+  static constexpr bool WIDE = 2 * N * 65 + 2 * NW <= LDS_FLOATS;
+  static constexpr int KPR = WIDE ? 64 / S : 48 / S;
+  static constexpr int COLS = S * KPR;
   static constexpr int ROUNDS = (M + KPR - 1) / KPR;
-  static constexpr int RW = 65;
-  static constexpr int BUF = N * RW;  // >= N * SW
-  static_assert(S >= 2 && S <= 16 && N % 4 == 0, "shape");
+  static constexpr int RW = COLS + 1;
+  static constexpr int BUF = N * RW > N * SW ? N * RW : N * SW;
+  static constexpr bool DEFER = 2 * BUF + 2 * NW <= LDS_FLOATS;  // room for separate partials
+  static_assert(S >= 2 && S <= 16 && N % 4 == 0 && KPR >= 1, "shape");
+  static_assert(DEFER || N * RW + NW <= BUF, "partials must fit the slack behind the image");
+  static_assert(2 * BUF <= LDS_FLOATS, "LDS");
 };
 
 template <int M, int L, int W>
@@ -1250,16 +1260,16 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ x, long lo
   using Cfg = Fused2Cfg<M, L>;
   using Stage = FusedStage<M, L, Cfg::NW>;
   constexpr int N = Cfg::N, NW = Cfg::NW, SW = Cfg::SW, STRIPS = Cfg::STRIPS, KPR = Cfg::KPR,
-                ROUNDS = Cfg::ROUNDS, RW = Cfg::RW;
+                ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, COLS = Cfg::COLS;
   constexpr int R0 = 2 * W, R1 = 2 * W + 1;
   int cur = 0, pslot = 0, pending_slot = 0;
   long long pending_m = -1;
   long long m = blockIdx.x;
-  auto finish = [&](int slot, long long mm) DCTS_LAMBDA_INLINE {
+  auto finish = [&](lds_ptr part, int slot, long long mm) DCTS_LAMBDA_INLINE {
     if (W == 0 && lane_in == 0) {
       float t = 0.f;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) t += partials[slot * NW + i];
+      for (int i = 0; i < NW; ++i) t += part[slot * NW + i];
       constexpr float sc = float(4.0 / (double(N) * double(N)));
       out[mm] = t * sc;
     }
@@ -1278,7 +1288,7 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ x, long lo
       lds_barrier();                                     // ... for everyone; the other buffer is free
       if constexpr (s == 0) {
         if (pending_m >= 0) {
-          finish(pending_slot, pending_m);
+          finish(partials, pending_slot, pending_m);
           pending_m = -1;
         }
       }
@@ -1338,31 +1348,42 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ x, long lo
       });
       lds_barrier();
       lane = launder(lane_in);
-      split_butterflies<M, L, NoHook, false, NW>(blk, RW, true, lane, W);
+      const bool colact = lane < COLS;
+      split_butterflies<M, L, NoHook, false, NW>(blk, RW, colact, lane, W);
       lds_barrier();
       dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
         constexpr int i = decltype(ii)::value;
         const int ln = launder(lane_in);
         float o[M];
-        split_role_transform<M, L, 2 * W + i>(blk + ln, RW, o);
+        split_role_transform<M, L, 2 * W + i>(blk + (ln < COLS ? ln : 0), RW, o);
         float er = 0.f;
         dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
           constexpr int k = decltype(ik)::value;
           er = fmaf(o[k], o[k], er);
         });
         asm volatile("" : "+v"(er));
-        e += er;
+        if (ln < COLS) e += er;
       });
     });
     e = wave_sum_dpp(e);
-    if (lane_in == 0) partials[pslot * NW + W] = e;
-    pending_m = m;
-    pending_slot = pslot;
-    pslot ^= 1;
+    if constexpr (Cfg::DEFER) {
+      if (lane_in == 0) partials[pslot * NW + W] = e;
+      pending_m = m;
+      pending_slot = pslot;
+      pslot ^= 1;
+    } else {
+      // no room for a partials array: it lives behind the image, and the sum is taken right away
+      // (the next strip only streams into this buffer after the next top-of-strip barrier)
+      lds_barrier();  // every wave has finished reading the image
+      const lds_ptr part = blk + N * RW;
+      if (lane_in == 0) part[W] = e;
+      lds_barrier();
+      finish(part, 0, m);
+    }
   }
   if (pending_m >= 0) {
     lds_barrier();
-    finish(pending_slot, pending_m);
+    finish(partials, pending_slot, pending_m);
   }
 }
 
@@ -1380,7 +1401,7 @@ __global__ __launch_bounds__((64 * Fused2Cfg<M, L>::NW), 2) void k_split_fused2(
   using Cfg = Fused2Cfg<M, L>;
   __shared__ __attribute__((aligned(16))) float buf0[Cfg::BUF];
   __shared__ __attribute__((aligned(16))) float buf1[Cfg::BUF];
-  __shared__ float partials[2 * Cfg::NW];
+  __shared__ float partials[Cfg::DEFER ? 2 * Cfg::NW : 1];
   fused2_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)partials,
                         threadIdx.x & 63, std::make_integer_sequence<int, Cfg::NW>{});
 }
@@ -2103,10 +2124,10 @@ inline int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
   return dctsi::dispatch_fused(N, &g, out, st);
 }
 
-// two roles per wave X(N, M, L): tiles the 16-wave kernels cannot park. (320 = 20 x 16 fits the
-// registers, 221 VGPRs, but its two LDS buffers need 166 464 bytes: 2.6 KB over the 160 KiB.)
+// two roles per wave X(N, M, L): tiles the 16-wave kernels cannot park (320 runs 48-column rounds
+// so that its two LDS buffers fit the 160 KiB exactly, see Fused2Cfg)
 #ifndef DCTS_FUSED2_TABLE
-#define DCTS_FUSED2_TABLE(X) X(288, 18, 4)
+#define DCTS_FUSED2_TABLE(X) X(288, 18, 4) X(320, 20, 4)
 #endif
 
 bool has_fused2(long long N) {

@@ -60,7 +60,7 @@ enum {
   DCTS_ALGO_PREFETCH = 4, /* codelet kernel with direct-to-LDS prefetch of the next maps (dense,
                              even-edge square tiles; measured equal to ALGO_CODELET, opt-in)     */
   DCTS_ALGO_FUSED = 5,    /* single-launch split kernel, intermediate tile parked in VGPRs
-                             (edges 72 ... 256; 288 with two roles per wave)                     */
+                             (edges 72 ... 256; 288 and 320 with two roles per wave)             */
   DCTS_ALGO_PIPE = 6,     /* the fused kernel software-pipelined: pass 2 of one map interleaved
                              with pass 1 of the next                                             */
   DCTS_ALGO_LANE = 7      /* one lane per map, both passes in registers (7x7, 9x9)              */

@@ -71,7 +71,7 @@ def test_direct_sizes(n):
 
 
 SPLIT = [72, 80, 112, 128, 144, 160, 224, 256, 288, 320]
-FUSED = [72, 80, 112, 128, 144, 160, 224, 256, 288]
+FUSED = [72, 80, 112, 128, 144, 160, 224, 256, 288, 320]
 
 
 @pytest.mark.parametrize("n", SPLIT)

@@ -15,7 +15,8 @@ rng = np.random.default_rng(7)
 bad = 0
 for it in range(iters):
     edge, algo, hi = [(224, dpa.ALGO_PIPE, 1500), (128, dpa.ALGO_PIPE, 4000), (7, dpa.ALGO_LANE, 300000),
-                      (9, dpa.ALGO_LANE, 200000), (224, dpa.ALGO_FUSED, 1500), (256, dpa.ALGO_FUSED, 1200)][it % 6]
+                      (9, dpa.ALGO_LANE, 200000), (224, dpa.ALGO_FUSED, 1500), (256, dpa.ALGO_FUSED, 1200), (288, dpa.ALGO_FUSED, 900),
+                      (320, dpa.ALGO_FUSED, 700)][it % 8]
     nmaps = int(rng.integers(1, hi))
     x = torch.relu(torch.randn(1, nmaps, edge, edge, device="cuda"))
     a = dpa.energy_nc(x, algo=algo)
