@@ -985,7 +985,12 @@ struct FusedCfg {
   static constexpr int S = 1 << L;
   static constexpr int SW = 64;
   static constexpr int STRIPS = (N + SW - 1) / SW;
-  static constexpr int RPR = (64 / M) >= 4 ? 4 : ((64 / M) >= 2 ? 2 : 1);  // role groups that fit the 64 lanes
+  // whole roles per unbalanced round: a power of two, or as many as fit the 64 lanes where that
+  // saves a round on the eight-wave kernels (144 = 18 x 8: rounds of 3+3+2 roles instead of four
+  // rounds of 2, 26.7 -> 30.9 % of peak; no gain measured at 160 = 10 x 16)
+  static constexpr int RPR_P2 = (64 / M) >= 4 ? 4 : ((64 / M) >= 2 ? 2 : 1);
+  static constexpr int RPR_FIT = (64 / M) > (1 << L) ? (1 << L) : ((64 / M) >= 1 ? 64 / M : 1);
+  static constexpr int RPR = (L <= 3 && (S + RPR_FIT - 1) / RPR_FIT < S / RPR_P2) ? RPR_FIT : RPR_P2;
   // which parked rows go into a pass-2 round:
   //  BALANCED: KPR = 64/S coefficients of EVERY role (all waves dump, equal work; M is padded up to
   //            ROUNDS*KPR with zero columns) - used where the padding wastes <= 1/6 of the columns;
@@ -996,10 +1001,10 @@ struct FusedCfg {
                                    !(M == 14 && L == 4) && M != 28;  // those two spill when every wave keeps its parked set live
   static constexpr int KPR = KPR_B;
   static constexpr int COLS = BALANCED ? S * KPR_B : RPR * M;  // pass-2 columns (lanes) per round
-  static constexpr int ROUNDS = BALANCED ? ROUNDS_B : S / RPR;
+  static constexpr int ROUNDS = BALANCED ? ROUNDS_B : (S + RPR - 1) / RPR;  // the last round may hold fewer roles
   static constexpr int RW = COLS | 1;                          // pass-2 image row stride (odd: conflict-free dump)
   static constexpr int BUF = (N * SW > N * RW ? N * SW : N * RW);  // floats per LDS buffer
-  static_assert(N % 4 == 0 && S % RPR == 0, "shape");
+  static_assert(N % 4 == 0, "shape");
 };
 
 // one direct-to-LDS instruction (64 lanes x 16 B) of a strip's staging: piece `it` of PIECES.
@@ -1158,7 +1163,9 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       DCTS_STAMP(7);
       lds_barrier();
       DCTS_STAMP(8);
-      const bool act = lane < COLS;
+      // columns of this round: all of them, or fewer whole roles in the last unbalanced round
+      constexpr int cols_r = Cfg::BALANCED ? COLS : ((S - r * RPR) < RPR ? (S - r * RPR) : RPR) * M;
+      const bool act = lane < cols_r;
       split_butterflies<M, L>(blk, RW, act, lane, ROLE);
       DCTS_STAMP(9);
       lds_barrier();
