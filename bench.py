@@ -139,6 +139,21 @@ def cpu_baseline(points, seconds):
     }
 
 
+def kernel_name(edge, per_tensor):
+    """The kernel dcts_energy_f32 / dcts_energy_multi_f32 (AUTO) runs for a square tile edge."""
+    if edge in (7, 9):
+        return "k_energy_lane_multi<%d>" % edge
+    if edge <= 64:
+        return ("k_energy_codelet<%d,%d>" if per_tensor else "k_energy_codelet_multi<%d,%d>") % (edge, edge)
+    if edge in (128, 224):
+        return "k_split_pipe (%dx%d)" % (edge, edge)
+    if edge in (288, 320):
+        return "k_split_fused2 (%dx%d)" % (edge, edge)
+    if edge in (72, 80, 112, 144, 160, 256):
+        return "k_split_fused (%dx%d)" % (edge, edge)
+    return "k_energy_direct (%dx%d)" % (edge, edge)
+
+
 def headline(lib, dev, stream_ptr, ws_fn):
     """SURVEY.md §8(d) headline micro-benchmarks: (N*C = 16384, 56x56) and (4096, 224x224);
     buffers rotated so the working set exceeds L2 + Infinity Cache."""
@@ -386,8 +401,7 @@ def main():
                        "units_rank0": len(bound), "load_imbalance": (max(load) / (sum(load) / world)) if world > 1 else 1.0},
             "GB_s_whole_step": total_cost * args.steps / dt / 1e9,
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_energy_codelet<%d,%d>" if args.per_tensor or dom_edge > 64 else
-                                    "k_energy_codelet_multi<%d,%d>") % (dom_edge, dom_edge),
+                         "kernel": kernel_name(dom_edge, args.per_tensor),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launches": n_launch, "avg_launch_us": dom_ms / n_launch * 1e3,
