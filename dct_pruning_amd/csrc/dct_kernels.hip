@@ -46,9 +46,9 @@ int dispatch_codelet_dma(int N, const void* geom, float* out, hipStream_t st);
 int dispatch_codelet_multi(int HP, int pad, const void* multi_geom, hipStream_t st);
 int dispatch_lane(int n, const void* multi_geom, hipStream_t st);
 int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStream_t st);
-int dispatch_fused(int N, const void* geom, float* out, hipStream_t st);
-int dispatch_fused2(int N, const void* geom, float* out, hipStream_t st);
-int dispatch_pipe(int N, const void* geom, float* out, hipStream_t st);
+int dispatch_fused(int N, const void* tile_batch, hipStream_t st);
+int dispatch_fused2(int N, const void* tile_batch, hipStream_t st);
+int dispatch_pipe(int N, const void* tile_batch, hipStream_t st);
 }  // namespace dctsi
 
 namespace {
@@ -231,6 +231,44 @@ struct MultiGeom {
   long long total_groups;
   int count;
 };
+
+// Dense tensors of one large tile shape as ONE map index space (fused / pipelined kernels): map m of
+// the batch is map m - begin[t] of tensor t. U2-Net-p hooks ten 288x288 tensors of 16 or 64 channels;
+// launched one by one at batch 12 they give a CU 0.75 or 3 maps each, together 16.5.
+constexpr int kTileItems = 32;
+struct TileBatch {
+  const float* x[kTileItems];
+  float* out[kTileItems];
+  long long begin[kTileItems + 1];  // begin[count] = total
+  long long map_elems;              // floats per map (dense: maps of a tensor are adjacent)
+  long long total;
+  int count;
+};
+__device__ __forceinline__ int tile_item(const TileBatch& tb, long long m) {
+  int t = 0;
+  while (t + 1 < tb.count && m >= tb.begin[t + 1]) ++t;  // wave-uniform
+  return __builtin_amdgcn_readfirstlane(t);
+}
+__device__ __forceinline__ const float* tile_in(const TileBatch& tb, long long m) {
+  const int t = tile_item(tb, m);
+  // explicitly wave-uniform (the raw direct-to-LDS loads take it as a scalar operand)
+  const unsigned long long a = reinterpret_cast<unsigned long long>(tb.x[t] + (m - tb.begin[t]) * tb.map_elems);
+  return reinterpret_cast<const float*>(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
+}
+__device__ __forceinline__ float* tile_out(const TileBatch& tb, long long m) {
+  const int t = tile_item(tb, m);
+  return tb.out[t] + (m - tb.begin[t]);
+}
+// one tensor, no table: the pipelined 14 x 16 kernel has neither the SGPRs nor the VGPRs to spare
+struct PlainMaps {
+  const float* x;
+  float* out;
+  long long map_elems;
+  long long total;
+};
+__device__ __forceinline__ const float* tile_in(const PlainMaps& pm, long long m) { return pm.x + m * pm.map_elems; }
+__device__ __forceinline__ float* tile_out(const PlainMaps& pm, long long m) { return pm.out + m; }
 
 template <int HP, int WP, int PAD>
 __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_codelet_multi(MultiGeom mg) {
@@ -1026,7 +1064,7 @@ struct FusedStage {
     const int q = qbase + lane;
     const int row = q >> 4, col = (q & 15) << 2;
     if (q < NQUADS && strip * SW + col < N) {
-      const float* base = in_b + strip * SW;
+      const float* base = in_b + strip * SW;                // wave-uniform (tile_in)
       const unsigned off = (unsigned)(row * N + col) * 4u;  // bytes
       const unsigned dst = (unsigned)(unsigned long long)(buf + 4 * qbase);
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
@@ -1055,22 +1093,20 @@ __device__ unsigned long long g_fused_stamps[16][16];
 #endif
 
 // sum of a map's per-wave partials in fixed order (wave 0, lane 0) and the final scale
-template <int M, int L, int ROLE>
-__device__ __forceinline__ void fused_finish(lds_ptr partials, int slot, long long m, float* __restrict__ out,
-                                             int lane) {
+template <int M, int L, int ROLE, class Src>
+__device__ __forceinline__ void fused_finish(lds_ptr partials, int slot, long long m, const Src& tb, int lane) {
   constexpr int S = 1 << L, N = M << L;
   if (ROLE == 0 && lane == 0) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < S; ++i) t += partials[slot * S + i];
     constexpr float sc = float(4.0 / (double(N) * double(N)));
-    out[m] = t * sc;
+    *tile_out(tb, m) = t * sc;
   }
 }
 
 template <int M, int L, int ROLE>
-__device__ __forceinline__ void fused_body(const float* __restrict__ x, long long map_stride, long long nmaps,
-                                           float* __restrict__ out, lds_ptr lds, lds_ptr partials, int lane) {
+__device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds_ptr partials, int lane) {
   using Cfg = FusedCfg<M, L>;
   constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, STRIPS = Cfg::STRIPS, COLS = Cfg::COLS, KPR = Cfg::KPR,
                 RPR = Cfg::RPR, ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, BUF = Cfg::BUF;
@@ -1081,13 +1117,14 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
   unsigned long long acc_[16] = {}, last_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
+  const long long nmaps = tb.total;
   if (m < nmaps) {
+    const float* first = tile_in(tb, m);
 #pragma unroll
-    for (int it = 0; it < FusedStage<M, L>::PIECES; ++it)
-      FusedStage<M, L>::piece_raw(x + m * map_stride, 0, lds, lane, ROLE, it);
+    for (int it = 0; it < FusedStage<M, L>::PIECES; ++it) FusedStage<M, L>::piece_raw(first, 0, lds, lane, ROLE, it);
   }
   for (; m < nmaps; m += gridDim.x) {
-    const float* in_b = x + m * map_stride;
+    const float* in_b = tile_in(tb, m);
     float parked[STRIPS][M];
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
@@ -1098,7 +1135,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       lds_barrier();                                   // ... for everyone; the other buffer is free
       if constexpr (s == 0) {
         if (pending_m >= 0) {
-          fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane);
+          fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
           pending_m = -1;
         }
       }
@@ -1108,7 +1145,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
       // the next strip (or the next map's first one) streams into the other buffer while this one
       // is transformed; its load instructions are trickled out between the butterflies
       const bool more = (s + 1 < STRIPS) || (m + gridDim.x < nmaps);
-      const float* nsrc = (s + 1 < STRIPS) ? in_b : x + (m + gridDim.x) * map_stride;
+      const float* nsrc = (s + 1 < STRIPS || !more) ? in_b : tile_in(tb, m + gridDim.x);
       constexpr int nstrip = (s + 1 < STRIPS) ? s + 1 : 0;
       int piece = more ? 0 : FusedStage<M, L>::PIECES;
       auto trickle = [&]() DCTS_LAMBDA_INLINE {
@@ -1193,7 +1230,7 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
   }
   if (pending_m >= 0) {
     lds_barrier();
-    fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane);
+    fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
   }
 #ifdef DCTS_FUSED_STAMPS
   if (lane == 0)
@@ -1202,10 +1239,9 @@ __device__ __forceinline__ void fused_body(const float* __restrict__ x, long lon
 }
 
 template <int M, int L, int... R>
-__device__ __forceinline__ void fused_dispatch(int role, const float* x, long long map_stride, long long nmaps,
-                                               float* out, lds_ptr lds, lds_ptr partials, int lane,
+__device__ __forceinline__ void fused_dispatch(int role, const TileBatch& tb, lds_ptr lds, lds_ptr partials, int lane,
                                                std::integer_sequence<int, R...>) {
-  ((role == R ? fused_body<M, L, R>(x, map_stride, nmaps, out, lds, partials, lane) : (void)0), ...);
+  ((role == R ? fused_body<M, L, R>(tb, lds, partials, lane) : (void)0), ...);
 }
 
 // waves per SIMD the register file allows: STRIPS*M parked values + the codelet's working set
@@ -1220,12 +1256,11 @@ constexpr int fused_waves_per_simd() {
 }
 
 template <int M, int L>
-__global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_split_fused(const float* __restrict__ x, long long map_stride,
-                                                              long long nmaps, float* __restrict__ out) {
+__global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_split_fused(TileBatch tb) {
   using Cfg = FusedCfg<M, L>;
   __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF];
   __shared__ float partials[2 * Cfg::S];
-  fused_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63,
+  fused_dispatch<M, L>(threadIdx.x >> 6, tb, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63,
                        std::make_integer_sequence<int, Cfg::S>{});
 }
 
@@ -1261,8 +1296,7 @@ struct Fused2Cfg {
 };
 
 template <int M, int L, int W>
-__device__ __forceinline__ void fused2_body(const float* __restrict__ x, long long map_stride, long long nmaps,
-                                            float* __restrict__ out, lds_ptr buf0, lds_ptr buf1, lds_ptr partials,
+__device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, lds_ptr buf1, lds_ptr partials,
                                             int lane_in) {
   using Cfg = Fused2Cfg<M, L>;
   using Stage = FusedStage<M, L, Cfg::NW>;
@@ -1272,21 +1306,23 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ x, long lo
   int cur = 0, pslot = 0, pending_slot = 0;
   long long pending_m = -1;
   long long m = blockIdx.x;
+  const long long nmaps = tb.total;
   auto finish = [&](lds_ptr part, int slot, long long mm) DCTS_LAMBDA_INLINE {
     if (W == 0 && lane_in == 0) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < NW; ++i) t += part[slot * NW + i];
       constexpr float sc = float(4.0 / (double(N) * double(N)));
-      out[mm] = t * sc;
+      *tile_out(tb, mm) = t * sc;
     }
   };
   if (m < nmaps) {
+    const float* first = tile_in(tb, m);
 #pragma unroll
-    for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(x + m * map_stride, 0, buf0, lane_in, W, it);
+    for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(first, 0, buf0, lane_in, W, it);
   }
   for (; m < nmaps; m += gridDim.x) {
-    const float* in_b = x + m * map_stride;
+    const float* in_b = tile_in(tb, m);
     float parked[2][STRIPS][M];
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
@@ -1302,7 +1338,7 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ x, long lo
       const lds_ptr buf = cur ? buf1 : buf0;
       const lds_ptr nxt = cur ? buf0 : buf1;
       const bool more = (s + 1 < STRIPS) || (m + gridDim.x < nmaps);
-      const float* nsrc = (s + 1 < STRIPS) ? in_b : x + (m + gridDim.x) * map_stride;
+      const float* nsrc = (s + 1 < STRIPS || !more) ? in_b : tile_in(tb, m + gridDim.x);
       constexpr int nstrip = (s + 1 < STRIPS) ? s + 1 : 0;
       if (more) {
 #pragma unroll
@@ -1395,22 +1431,19 @@ __device__ __forceinline__ void fused2_body(const float* __restrict__ x, long lo
 }
 
 template <int M, int L, int... Wv>
-__device__ __forceinline__ void fused2_dispatch(int wave, const float* x, long long map_stride, long long nmaps,
-                                                float* out, lds_ptr buf0, lds_ptr buf1, lds_ptr partials, int lane,
-                                                std::integer_sequence<int, Wv...>) {
-  ((wave == Wv ? fused2_body<M, L, Wv>(x, map_stride, nmaps, out, buf0, buf1, partials, lane) : (void)0), ...);
+__device__ __forceinline__ void fused2_dispatch(int wave, const TileBatch& tb, lds_ptr buf0, lds_ptr buf1,
+                                                lds_ptr partials, int lane, std::integer_sequence<int, Wv...>) {
+  ((wave == Wv ? fused2_body<M, L, Wv>(tb, buf0, buf1, partials, lane) : (void)0), ...);
 }
 
 template <int M, int L>
-__global__ __launch_bounds__((64 * Fused2Cfg<M, L>::NW), 2) void k_split_fused2(const float* __restrict__ x,
-                                                                                 long long map_stride, long long nmaps,
-                                                                                 float* __restrict__ out) {
+__global__ __launch_bounds__((64 * Fused2Cfg<M, L>::NW), 2) void k_split_fused2(TileBatch tb) {
   using Cfg = Fused2Cfg<M, L>;
   __shared__ __attribute__((aligned(16))) float buf0[Cfg::BUF];
   __shared__ __attribute__((aligned(16))) float buf1[Cfg::BUF];
   __shared__ float partials[Cfg::DEFER ? 2 * Cfg::NW : 1];
-  fused2_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)partials,
-                        threadIdx.x & 63, std::make_integer_sequence<int, Cfg::NW>{});
+  fused2_dispatch<M, L>(threadIdx.x >> 6, tb, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)partials, threadIdx.x & 63,
+                        std::make_integer_sequence<int, Cfg::NW>{});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1463,9 +1496,8 @@ __device__ __forceinline__ float& pipe_slot(float (&P)[T][T][KPR]) {
 }
 
 template <int M, int L, int ROLE>
-__device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long map_stride, long long nmaps,
-                                          float* __restrict__ out, lds_ptr buf0, lds_ptr buf1, lds_ptr parkbuf, lds_ptr partials,
-                                          int lane_in) {
+__device__ __forceinline__ void pipe_body(const PlainMaps& tb, lds_ptr buf0, lds_ptr buf1, lds_ptr parkbuf,
+                                          lds_ptr partials, int lane_in) {
   using Cfg = PipeCfg<M, L>;
   using Stage = FusedStage<M, L>;
   constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, T = Cfg::T, KPR = Cfg::KPR, RW = Cfg::RW, BUF = Cfg::BUF;
@@ -1477,9 +1509,11 @@ __device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long
   unsigned long long acc_[16] = {}, last_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
+  const long long nmaps = tb.total;
   if (m_cur < nmaps) {
+    const float* first = tile_in(tb, m_cur);
 #pragma unroll
-    for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(x + m_cur * map_stride, 0, buf0, lane_in, ROLE, it);
+    for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(first, 0, buf0, lane_in, ROLE, it);
   }
 
   // The direct-to-LDS loads of a strip are issued in four instalments spread over one whole step
@@ -1499,7 +1533,7 @@ __device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long
   auto iteration = [&](auto par, auto hp, auto hc) DCTS_LAMBDA_INLINE {
     constexpr int PAR = decltype(par)::value;  // layout of the previous map; the current one gets 1 - PAR
     constexpr bool have_prev = decltype(hp)::value, have_cur = decltype(hc)::value;
-    const float* in_b = x + (have_cur ? m_cur : 0) * map_stride;
+    const float* in_b = tile_in(tb, have_cur ? m_cur : 0);
     float e = 0.f;
     dcts::static_for<T>([&](auto ir) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(ir)::value;
@@ -1516,7 +1550,7 @@ __device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long
         DCTS_STAMP(0);
         if constexpr (r == 0) {
           if (pending_m >= 0) {
-            fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane_in);
+            fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane_in);
             pending_m = -1;
           }
         }
@@ -1569,7 +1603,7 @@ __device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long
         lds_barrier();                                   // ... everyone's; img has been consumed
         DCTS_STAMP(7);
         const bool more = (r + 1 < T) || (m_cur + gridDim.x < nmaps);
-        const float* nsrc = (r + 1 < T) ? in_b : x + (m_cur + gridDim.x) * map_stride;
+        const float* nsrc = (r + 1 < T || !more) ? in_b : tile_in(tb, m_cur + gridDim.x);
         constexpr int nstrip = (r + 1 < T) ? r + 1 : 0;
         // the step that transforms the next strip starts with a pass-2 round (which issues the other
         // two instalments) unless this is the first map of the workgroup
@@ -1635,7 +1669,7 @@ __device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long
   }
   if (pending_m >= 0) {
     lds_barrier();
-    fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, out, lane_in);
+    fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane_in);
   }
 #ifdef DCTS_FUSED_STAMPS
   if (lane_in == 0)
@@ -1644,22 +1678,22 @@ __device__ __forceinline__ void pipe_body(const float* __restrict__ x, long long
 }
 
 template <int M, int L, int... R>
-__device__ __forceinline__ void pipe_dispatch(int role, const float* x, long long map_stride, long long nmaps,
-                                              float* out, lds_ptr buf0, lds_ptr buf1, lds_ptr park, lds_ptr partials,
-                                              int lane, std::integer_sequence<int, R...>) {
-  ((role == R ? pipe_body<M, L, R>(x, map_stride, nmaps, out, buf0, buf1, park, partials, lane) : (void)0), ...);
+__device__ __forceinline__ void pipe_dispatch(int role, const PlainMaps& tb, lds_ptr buf0, lds_ptr buf1, lds_ptr park,
+                                              lds_ptr partials, int lane, std::integer_sequence<int, R...>) {
+  ((role == R ? pipe_body<M, L, R>(tb, buf0, buf1, park, partials, lane) : (void)0), ...);
 }
 
 template <int M, int L>
 __global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_split_pipe(const float* __restrict__ x, long long map_stride,
                                                              long long nmaps, float* __restrict__ out) {
+  const PlainMaps tb{x, out, map_stride, nmaps};
   using Cfg = PipeCfg<M, L>;
   __shared__ __attribute__((aligned(16))) float buf0[Cfg::BUF];
   __shared__ __attribute__((aligned(16))) float buf1[Cfg::BUF];
   __shared__ float park[Cfg::T * Cfg::NP * 64 * Cfg::S > 0 ? Cfg::T * Cfg::NP * 64 * Cfg::S : 1];
   __shared__ float partials[2 * Cfg::S];
-  pipe_dispatch<M, L>(threadIdx.x >> 6, x, map_stride, nmaps, out, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)park,
-                      (lds_ptr)partials, threadIdx.x & 63, std::make_integer_sequence<int, Cfg::S>{});
+  pipe_dispatch<M, L>(threadIdx.x >> 6, tb, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)park, (lds_ptr)partials,
+                      threadIdx.x & 63, std::make_integer_sequence<int, Cfg::S>{});
 }
 
 // out[b] = scale * sum of the map's ROLES*STRIPS partials, fixed order
@@ -2092,8 +2126,7 @@ bool has_fused(long long N) {
 }
 
 template <int M, int L>
-int launch_fused(const MapGeom& g, float* out, hipStream_t st) {
-  const float* x0 = g.x + (long long)g.c_begin * g.strideC;
+int launch_fused(const TileBatch& tb, hipStream_t st) {
   // persistent grid: exactly the workgroups one residency holds (LDS- or register-limited)
   static const int per_cu = [] {
     int n = 0;
@@ -2102,21 +2135,19 @@ int launch_fused(const MapGeom& g, float* out, hipStream_t st) {
     return n;
   }();
   const long long cap = (long long)kNumCU * per_cu;
-  const long long grid = g.nmaps < cap ? g.nmaps : cap;
-  hipLaunchKernelGGL((k_split_fused<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, x0, g.strideC, g.nmaps,
-                     out);
+  const long long grid = tb.total < cap ? tb.total : cap;
+  hipLaunchKernelGGL((k_split_fused<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, tb);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 #if DCTS_PART(3)
 namespace dctsi {
-int dispatch_fused(int N, const void* geom, float* out, hipStream_t st) {
-  const MapGeom& g = *static_cast<const MapGeom*>(geom);
-
+int dispatch_fused(int N, const void* tile_batch, hipStream_t st) {
+  const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
 #define DCTS_CASE(N_, M_, L_) \
   case N_:                    \
-    return launch_fused<M_, L_>(g, out, st);
+    return launch_fused<M_, L_>(tb, st);
   switch (N) {
     DCTS_FUSED_TABLE(DCTS_CASE)
     default:
@@ -2127,9 +2158,7 @@ int dispatch_fused(int N, const void* geom, float* out, hipStream_t st) {
 }  // namespace dctsi
 #endif
 namespace {
-inline int dispatch_fused(int N, const MapGeom& g, float* out, hipStream_t st) {
-  return dctsi::dispatch_fused(N, &g, out, st);
-}
+inline int dispatch_fused(int N, const TileBatch& tb, hipStream_t st) { return dctsi::dispatch_fused(N, &tb, st); }
 
 // two roles per wave X(N, M, L): tiles the 16-wave kernels cannot park (320 runs 48-column rounds
 // so that its two LDS buffers fit the 160 KiB exactly, see Fused2Cfg)
@@ -2146,22 +2175,20 @@ bool has_fused2(long long N) {
 }
 
 template <int M, int L>
-int launch_fused2(const MapGeom& g, float* out, hipStream_t st) {
-  const float* x0 = g.x + (long long)g.c_begin * g.strideC;
+int launch_fused2(const TileBatch& tb, hipStream_t st) {
   const long long cap = kNumCU;  // LDS: one workgroup per CU
-  const long long grid = g.nmaps < cap ? g.nmaps : cap;
-  hipLaunchKernelGGL((k_split_fused2<M, L>), dim3((unsigned)grid), dim3(64 * Fused2Cfg<M, L>::NW), 0, st, x0, g.strideC,
-                     g.nmaps, out);
+  const long long grid = tb.total < cap ? tb.total : cap;
+  hipLaunchKernelGGL((k_split_fused2<M, L>), dim3((unsigned)grid), dim3(64 * Fused2Cfg<M, L>::NW), 0, st, tb);
   return (int)hipGetLastError();
 }
 }  // namespace
 #if DCTS_PART(3)
 namespace dctsi {
-int dispatch_fused2(int N, const void* geom, float* out, hipStream_t st) {
-  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+int dispatch_fused2(int N, const void* tile_batch, hipStream_t st) {
+  const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
 #define DCTS_CASE(N_, M_, L_) \
   case N_:                    \
-    return launch_fused2<M_, L_>(g, out, st);
+    return launch_fused2<M_, L_>(tb, st);
   switch (N) {
     DCTS_FUSED2_TABLE(DCTS_CASE)
     default:
@@ -2189,8 +2216,7 @@ bool has_pipe(long long N) {
 }
 
 template <int M, int L>
-int launch_pipe(const MapGeom& g, float* out, hipStream_t st) {
-  const float* x0 = g.x + (long long)g.c_begin * g.strideC;
+int launch_pipe(const TileBatch& tb, hipStream_t st) {  // one tensor per launch (PlainMaps)
   static const int per_cu = [] {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_split_pipe<M, L>, 64 << L, 0) != hipSuccess || n < 1)
@@ -2198,20 +2224,25 @@ int launch_pipe(const MapGeom& g, float* out, hipStream_t st) {
     return n;
   }();
   const long long cap = (long long)kNumCU * per_cu;
-  const long long grid = g.nmaps < cap ? g.nmaps : cap;
-  hipLaunchKernelGGL((k_split_pipe<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, x0, g.strideC, g.nmaps, out);
-  return (int)hipGetLastError();
+  int rc = 0;
+  for (int i = 0; i < tb.count && !rc; ++i) {
+    const long long nm = tb.begin[i + 1] - tb.begin[i];
+    const long long grid = nm < cap ? nm : cap;
+    hipLaunchKernelGGL((k_split_pipe<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, tb.x[i], tb.map_elems, nm,
+                       tb.out[i]);
+    rc = (int)hipGetLastError();
+  }
+  return rc;
 }
 
 }  // namespace
 #if DCTS_PART(4)
 namespace dctsi {
-int dispatch_pipe(int N, const void* geom, float* out, hipStream_t st) {
-  const MapGeom& g = *static_cast<const MapGeom*>(geom);
-
+int dispatch_pipe(int N, const void* tile_batch, hipStream_t st) {
+  const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
 #define DCTS_CASE(N_, M_, L_) \
   case N_:                    \
-    return launch_pipe<M_, L_>(g, out, st);
+    return launch_pipe<M_, L_>(tb, st);
   switch (N) {
     DCTS_PIPE_TABLE(DCTS_CASE)
     default:
@@ -2222,9 +2253,7 @@ int dispatch_pipe(int N, const void* geom, float* out, hipStream_t st) {
 }  // namespace dctsi
 #endif
 namespace {
-inline int dispatch_pipe(int N, const MapGeom& g, float* out, hipStream_t st) {
-  return dctsi::dispatch_pipe(N, &g, out, st);
-}
+inline int dispatch_pipe(int N, const TileBatch& tb, hipStream_t st) { return dctsi::dispatch_pipe(N, &tb, st); }
 
 }  // namespace
 #if DCTS_PART(2)
@@ -2350,6 +2379,28 @@ bool has_codelet(long long HP, long long WP) {
   return false;
 }
 
+// which single-launch large-tile kernel serves an edge: 0 none, 1 fused, 2 fused with two roles per
+// wave, 3 pipelined (AUTO order: pipelined, two-roles, fused)
+int tile_family(int HP, int algo) {
+  if (algo == DCTS_ALGO_PIPE) return has_pipe(HP) && has_fused(HP) ? 3 : 0;
+  if (algo == DCTS_ALGO_AUTO && has_pipe(HP) && has_fused(HP)) return 3;
+  if (has_fused2(HP) && (algo == DCTS_ALGO_FUSED || DCTS_FUSED2_AUTO)) return 2;
+  if (has_fused(HP)) return 1;
+  return 0;
+}
+int dispatch_tile_family(int fam, int HP, const TileBatch& tb, hipStream_t st) {
+  switch (fam) {
+    case 3:
+      return dispatch_pipe(HP, tb, st);
+    case 2:
+      return dctsi::dispatch_fused2(HP, &tb, st);
+    case 1:
+      return dispatch_fused(HP, tb, st);
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+}
+
 template <bool STORE>
 int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_t strideN,
         int64_t strideC, int64_t strideH, int64_t strideW, int32_t c_begin, int32_t c_count,
@@ -2413,15 +2464,23 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
                           strideC == H * W;
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
     const bool aligned16 = (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
-    const bool fused2_ok = split_ok && has_fused2(HP) && aligned16;
-    if (fused2_ok && (algo == DCTS_ALGO_FUSED || (algo == DCTS_ALGO_AUTO && DCTS_FUSED2_AUTO)))
-      return dctsi::dispatch_fused2((int)HP, &g, out, st);
-    const bool fused_ok = split_ok && has_fused(HP) && aligned16;
-    if (algo == DCTS_ALGO_FUSED && !fused_ok) return DCTS_E_UNSUPPORTED;
-    const bool pipe_ok = fused_ok && has_pipe(HP);
-    if (algo == DCTS_ALGO_PIPE) return pipe_ok ? dispatch_pipe((int)HP, g, out, st) : DCTS_E_UNSUPPORTED;
-    if (pipe_ok && algo == DCTS_ALGO_AUTO) return dispatch_pipe((int)HP, g, out, st);
-    if (fused_ok && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED)) return dispatch_fused((int)HP, g, out, st);
+    if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE) {
+      const int fam = (split_ok && aligned16) ? tile_family((int)HP, algo) : 0;
+      if (fam) {
+        TileBatch tb;
+        for (int i = 0; i < kTileItems; ++i) {
+          tb.x[i] = x + (long long)c_begin * strideC;
+          tb.out[i] = out;
+          tb.begin[i] = 0;
+        }
+        tb.begin[1] = tb.begin[kTileItems] = g.nmaps;
+        tb.map_elems = strideC;
+        tb.total = g.nmaps;
+        tb.count = 1;
+        return dispatch_tile_family(fam, (int)HP, tb, st);
+      }
+      if (algo != DCTS_ALGO_AUTO) return DCTS_E_UNSUPPORTED;
+    }
     if (split_ok && algo != DCTS_ALGO_DIRECT) {
       const SplitWs sws = split_ws(g.nmaps, (int)HP);
       if (!workspace || workspace_bytes < sws.total) return DCTS_E_WORKSPACE;
@@ -2581,14 +2640,47 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
     }
     return DCTS_OK;
   }
-  // shapes without a codelet: one call per tensor (fused / split / direct), same stream
+  // large tiles with a single-launch kernel: the dense tensors go into ONE launch per 32 of them (their
+  // maps form one index space: a CU that would get a fraction of a map from one small tensor now
+  // draws from all of them); results are those of one call per tensor, bit for bit
+  const int fam = (pad == 0 && H == W && has_split(HP, WP)) ? tile_family((int)HP, DCTS_ALGO_AUTO) : 0;
+  TileBatch tb;
+  int nb = 0;
+  auto flush = [&]() -> int {
+    if (!nb) return DCTS_OK;
+    for (int i = nb; i < kTileItems; ++i) {
+      tb.x[i] = tb.x[0];
+      tb.out[i] = tb.out[0];
+      tb.begin[i + 1] = tb.begin[nb];
+    }
+    tb.map_elems = H * W;
+    tb.total = tb.begin[nb];
+    tb.count = nb;
+    nb = 0;
+    return dispatch_tile_family(fam, (int)HP, tb, st);
+  };
   for (int32_t i = 0; i < count; ++i) {
     const dcts_tensor_item& t = items[i];
+    const float* x0 = t.x + (int64_t)t.c_begin * t.strideC;
+    const bool dense = fam && t.strideC == H * W && (t.N == 1 || t.strideN == (int64_t)t.c_count * t.strideC) &&
+                       (reinterpret_cast<uintptr_t>(x0) & 15) == 0;
+    if (dense) {
+      if (nb == 0) tb.begin[0] = 0;
+      tb.x[nb] = x0;
+      tb.out[nb] = t.out_nc;
+      tb.begin[nb + 1] = tb.begin[nb] + t.N * (int64_t)t.c_count;
+      if (++nb == kTileItems) {
+        const int rc = flush();
+        if (rc) return rc;
+      }
+      continue;
+    }
+    // everything else: one call per tensor (split / direct), same stream
     const int rc = run<false>(t.x, t.N, t.C_total, H, W, t.strideN, t.strideC, W, 1, t.c_begin, t.c_count,
                               pad_front_if_odd, t.out_nc, workspace, workspace_bytes, stream, DCTS_ALGO_AUTO);
     if (rc) return rc;
   }
-  return DCTS_OK;
+  return flush();
 }
 
 int dcts_running_mean_update_multi_f32(const dcts_update_desc* descs, int32_t count, void* stream) {

@@ -317,11 +317,13 @@ def test_lane_per_map_kernel(n):
 
 
 @pytest.mark.parametrize("n,pad", [(8, False), (7, False), (9, False), (9, True), (14, False), (32, False), (56, False), (24, False),
-                                   (128, False)])
+                                   (72, False), (128, False), (224, False), (288, False)])
 def test_energy_multi_matches_single_calls(n, pad):
     """dcts_energy_multi_f32: many tensors of one tile shape in one launch == one call per tensor
     (bitwise), including channel slices, batch-strided views and more than 32 items (chunking)."""
-    base = [synth(2 + i % 3, 5 + 7 * (i % 4), n, n, 400 + i) for i in range(5 if n >= 56 else 37)]
+    # large tiles: dense tensors are batched into one fused / pipelined launch (up to 32 per launch)
+    nten = 37 if n < 56 else (35 if n == 72 else 5)
+    base = [synth(2 + i % 3, 5 + 7 * (i % 4), n, n, 400 + i) for i in range(nten)]
     items = []
     for i, x in enumerate(base):
         xc = x.cuda()
