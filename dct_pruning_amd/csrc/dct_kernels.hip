@@ -29,7 +29,7 @@
 #include "codelet_sizes.h"
 #include "dct_codelets.hpp"
 
-// The file is compiled five times in parallel (Makefile: -DDCTS_TU=1..5), each translation unit
+// The file is compiled six times in parallel (Makefile: -DDCTS_TU=1..6), each translation unit
 // instantiating one kernel family; DCTS_TU=0 (default) builds everything in one unit. Only the
 // dispatchers that instantiate kernels cross units: they are declared here with the geometry
 // structs passed as opaque pointers (the structs live in the anonymous namespace of every unit).
@@ -39,7 +39,7 @@
 #ifndef DCTS_FUSED2_AUTO
 #define DCTS_FUSED2_AUTO 1  // AUTO uses the two-roles-per-wave fused kernel where it exists (288: 31 % vs 18 %, 320: 31 % vs 17 % of the HBM peak)
 #endif
-#define DCTS_PART(n) (DCTS_TU == 0 || DCTS_TU == (n))  // 1 codelet+lane, 2 two-launch split, 3 fused, 4 pipelined, 5 rest + C ABI
+#define DCTS_PART(n) (DCTS_TU == 0 || DCTS_TU == (n))  // 1 codelet+lane, 2 two-launch split, 3 fused, 4 pipelined, 5 rest + C ABI, 6 fused with two roles per wave
 namespace dctsi {
 int dispatch_codelet(int store, int HP, int WP, int pad, const void* geom, float* out, hipStream_t st);
 int dispatch_codelet_dma(int N, const void* geom, float* out, hipStream_t st);
@@ -2182,7 +2182,7 @@ int launch_fused2(const TileBatch& tb, hipStream_t st) {
   return (int)hipGetLastError();
 }
 }  // namespace
-#if DCTS_PART(3)
+#if DCTS_PART(6)
 namespace dctsi {
 int dispatch_fused2(int N, const void* tile_batch, hipStream_t st) {
   const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
