@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=None, help="default 256 (u2netp: 12, README.md:222 of the reference)")
     ap.add_argument("--net", default="resnet_50")
+    ap.add_argument("--input-size", type=int, default=None,
+                    help="u2netp only: input crop edge (reference crop 288, BASELINE config 5 names 320)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-headline", action="store_true")
     ap.add_argument("--per-tensor", action="store_true",
@@ -185,15 +187,37 @@ def headline(lib, dev, stream_ptr, ws_fn):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` on its own: start the N ranks as a CHILD torch.distributed.run (this
+    process has not touched the GPU and never execs), relay the child's output (rank 0 prints the one
+    JSON line) and its exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.batch is None:
+        args.batch = 12 if args.net == "u2netp" else 256
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or without a launcher)"
+                 % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback in the product path)")
     # rehearsal mode for a one-GPU box: DCTS_BENCH_REHEARSE=1 puts every rank on cuda:0 and runs the
@@ -218,7 +242,9 @@ def main():
     def ws_fn(n, c, h, w):
         return _workspace(dev, stream_ptr, lib.dcts_workspace_bytes(n, c, h, w))
 
-    points = schedules.SCHEDULES[args.net]()
+    if args.input_size is not None and args.net != "u2netp":
+        sys.exit("--input-size applies to --net u2netp only")
+    points = schedules.SCHEDULES[args.net](args.input_size) if args.input_size else schedules.SCHEDULES[args.net]()
     N = args.batch
     scored = [schedules.scored_shape(p) for p in points]
     chans = [s[1] for s in scored]

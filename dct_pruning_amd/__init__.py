@@ -15,6 +15,7 @@ from .ops import (  # noqa: F401
     ALGO_LANE,
     ALGO_PREFETCH,
     ALGO_SPLIT,
+    ALGO_TILE2D,
     batch_sum,
     dct2d,
     energy_multi,
@@ -22,4 +23,4 @@ from .ops import (  # noqa: F401
     has_codelet,
 )
 
-__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE"]
+__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE", "ALGO_TILE2D"]

@@ -80,17 +80,26 @@ class DeviceBatchAccumulator:
 
     def add_tensor(self, key, x, c_begin, c_count, pad):
         """Deferred scoring: keep a reference to the hooked tensor; its energy is computed at flush time
-        together with every other pending tensor of the same tile shape (ops.energy_multi). The caller
-        guarantees nothing overwrites the tensor before the flush (true for the reference's nets: hooked
-        tensors are ReLU / pool / concat outputs that later layers only read)."""
+        together with every other pending tensor of the same tile shape (ops.energy_multi). Nothing may
+        overwrite the tensor before the flush (true for the reference's nets: hooked tensors are ReLU /
+        pool / concat outputs that later layers only read). That is checked, not assumed: the tensor's
+        autograd version counter is recorded here and compared at flush time; a net with an in-place op
+        downstream of a hooked module (inplace ReLU, `out += ...`) raises instead of scoring overwritten
+        data - use the per-hook mode (deferred=False) for such nets."""
         if key in self.pending or key in self.pending_x:
             self.flush()
-        self.pending_x[key] = (x, c_begin, c_count, pad)
+        self.pending_x[key] = (x, c_begin, c_count, pad, x._version)
 
     def _score_pending_tensors(self):
         from . import ops
         groups = {}
-        for key, (x, cb, cc, pad) in self.pending_x.items():
+        for key, (x, cb, cc, pad, version) in self.pending_x.items():
+            if x._version != version:
+                self.pending_x.clear()
+                raise RuntimeError(
+                    "deferred scoring: the tensor hooked at %r was modified in place after its hook fired "
+                    "(version %d -> %d); scores would be those of the overwritten data. Run without "
+                    "--deferred / deferred=False for this network." % (key, version, x._version))
             groups.setdefault((x.shape[2], x.shape[3], bool(pad)), []).append(key)
         for (h, w, pad), keys in groups.items():
             outs = ops.energy_multi([self.pending_x[k][:3] for k in keys], pad_front_if_odd=pad)

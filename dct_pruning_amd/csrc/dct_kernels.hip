@@ -28,6 +28,7 @@
 #include "../../include/dctscore.h"
 #include "codelet_sizes.h"
 #include "dct_codelets.hpp"
+#include "split_roles.hpp"
 
 // The file is compiled six times in parallel (Makefile: -DDCTS_TU=1..6), each translation unit
 // instantiating one kernel family; DCTS_TU=0 (default) builds everything in one unit. Only the
@@ -49,13 +50,11 @@ int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStre
 int dispatch_fused(int N, const void* tile_batch, hipStream_t st);
 int dispatch_fused2(int N, const void* tile_batch, hipStream_t st);
 int dispatch_pipe(int N, const void* tile_batch, hipStream_t st);
+int dispatch_tile2d(int N, const void* tile_batch, hipStream_t st);  // tile2d.hip
 }  // namespace dctsi
 
 namespace {
 
-// LDS pointers stay in address space 3 end to end (see the split family for why)
-using lds_ptr = __attribute__((address_space(3))) float*;
-using lds_cptr = const __attribute__((address_space(3))) float*;
 
 struct MapGeom {
   const float* x;
@@ -232,43 +231,6 @@ struct MultiGeom {
   int count;
 };
 
-// Dense tensors of one large tile shape as ONE map index space (fused / pipelined kernels): map m of
-// the batch is map m - begin[t] of tensor t. U2-Net-p hooks ten 288x288 tensors of 16 or 64 channels;
-// launched one by one at batch 12 they give a CU 0.75 or 3 maps each, together 16.5.
-constexpr int kTileItems = 32;
-struct TileBatch {
-  const float* x[kTileItems];
-  float* out[kTileItems];
-  long long begin[kTileItems + 1];  // begin[count] = total
-  long long map_elems;              // floats per map (dense: maps of a tensor are adjacent)
-  long long total;
-  int count;
-};
-__device__ __forceinline__ int tile_item(const TileBatch& tb, long long m) {
-  int t = 0;
-  while (t + 1 < tb.count && m >= tb.begin[t + 1]) ++t;  // wave-uniform
-  return __builtin_amdgcn_readfirstlane(t);
-}
-__device__ __forceinline__ const float* tile_in(const TileBatch& tb, long long m) {
-  const int t = tile_item(tb, m);
-  // explicitly wave-uniform (the raw direct-to-LDS loads take it as a scalar operand)
-  const unsigned long long a = reinterpret_cast<unsigned long long>(tb.x[t] + (m - tb.begin[t]) * tb.map_elems);
-  return reinterpret_cast<const float*>(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                                        (unsigned)__builtin_amdgcn_readfirstlane((int)a));
-}
-__device__ __forceinline__ float* tile_out(const TileBatch& tb, long long m) {
-  const int t = tile_item(tb, m);
-  return tb.out[t] + (m - tb.begin[t]);
-}
-// one tensor, no table: the pipelined 14 x 16 kernel has neither the SGPRs nor the VGPRs to spare
-struct PlainMaps {
-  const float* x;
-  float* out;
-  long long map_elems;
-  long long total;
-};
-__device__ __forceinline__ const float* tile_in(const PlainMaps& pm, long long m) { return pm.x + m * pm.map_elems; }
-__device__ __forceinline__ float* tile_out(const PlainMaps& pm, long long m) { return pm.out + m; }
 
 template <int HP, int WP, int PAD>
 __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_codelet_multi(MultiGeom mg) {
@@ -565,53 +527,6 @@ __global__ __launch_bounds__((64 * CodeletCfg<N, N>::WAVES)) void k_energy_codel
 // T[b][line][role*M + k] through a per-wave LDS transpose (coalesced stores), so the second launch
 // of the same kernel transforms the other axis. Final pass: squares are reduced per wave into
 // partial sums which k_split_reduce adds in fixed order.
-template <int N>
-struct SplitRoot {
-  static constexpr int len = N;
-  static constexpr bool is4 = false;
-  template <int J>
-  static __device__ __forceinline__ float in(const float* col, int rs) {
-    return col[J * rs];
-  }
-  static constexpr double wt(bool zero) { return zero ? 0.70710678118654752440 : 1.0; }  // global DC
-};
-
-template <class P, int WHICH>
-struct SplitNode {
-  static constexpr int len = P::len / 2;
-  static constexpr bool is4 = (!P::is4) && WHICH == 1;
-  template <int J>
-  static __device__ __forceinline__ float in(const float* col, int rs) {
-    const float y0 = P::template in<J>(col, rs);
-    const float y1 = P::template in<P::len - 1 - J>(col, rs);
-    if constexpr (!P::is4) {
-      return WHICH == 0 ? y0 + y1 : y0 - y1;
-    } else {
-      constexpr float c = float(dcts::cospi_frac(2 * J + 1, 4 * P::len));
-      constexpr float sn = float(dcts::sinpi_frac(2 * J + 1, 4 * P::len));
-      if constexpr (WHICH == 0) {
-        return y0 * c + y1 * sn;
-      } else {
-        constexpr float sg = (J % 2 == 0) ? 1.f : -1.f;
-        return y1 * (sg * c) - y0 * (sg * sn);
-      }
-    }
-  }
-  // amplitude weight of an output of this node; `zero`: its index in this node's output space is 0
-  static constexpr double wt(bool zero) {
-    const double f = (P::is4 && !zero) ? 1.41421356237309504880 : 1.0;
-    return f * P::wt(zero && WHICH == 0);
-  }
-};
-
-template <int N, int L, int R>
-struct RoleLeaf {
-  using type = SplitNode<typename RoleLeaf<N, L - 1, (R >> 1)>::type, (R & 1)>;
-};
-template <int N>
-struct RoleLeaf<N, 0, 0> {
-  using type = SplitRoot<N>;
-};
 
 template <int M, int L>
 struct SplitCfg {
@@ -628,94 +543,6 @@ struct SplitCfg {
   static constexpr int LDS_NONFINAL = IN_LDS > TR_LDS ? IN_LDS : TR_LDS;
 };
 
-// The role butterflies as an in-place network on the 2^L mirrored samples of one (p, line):
-// slot s holds row s*M + p (s even) or s*M + M-1-p (s odd) of the strip. Level by level the
-// samples of a node are paired (index j with n-1-j), the pair is replaced by the inputs of the
-// node's two children, and after L levels every slot holds one input sample of one role. All
-// structure (which slots pair up, which role ends where, whether a role sees its samples in
-// ascending or descending p) is compile-time; only the rotation constants depend on p (table).
-template <int L>
-struct RolePlan {
-  static constexpr int S = 1 << L;
-  static constexpr int NOPS = L * (S / 2);
-  int op_a[NOPS > 0 ? NOPS : 1] = {}, op_b[NOPS > 0 ? NOPS : 1] = {}, op_rot[NOPS > 0 ? NOPS : 1] = {};
-  int nrot = 0;
-  int rot_seg[NOPS > 0 ? NOPS : 1] = {}, rot_asc[NOPS > 0 ? NOPS : 1] = {}, rot_c[NOPS > 0 ? NOPS : 1] = {};
-  int slot_of_role[S] = {}, asc_of_role[S] = {}, is4_of_role[S] = {};
-  constexpr RolePlan() {
-    int node[S] = {}, seg[S] = {}, asc[S] = {}, is4[S] = {};
-    for (int s = 0; s < S; ++s) {
-      seg[s] = s;
-      asc[s] = (s % 2 == 0) ? 1 : 0;
-    }
-    int c = S, n = 0;
-    for (int lvl = 0; lvl < L; ++lvl) {
-      int nnode[S] = {}, nis4[S] = {}, nseg[S] = {}, nasc[S] = {};
-      for (int i = 0; i < S; ++i) {
-        if (seg[i] >= c / 2) continue;
-        int k = -1;
-        for (int t = 0; t < S; ++t)
-          if (node[t] == node[i] && seg[t] == c - 1 - seg[i]) k = t;
-        op_a[n] = i;
-        op_b[n] = k;
-        if (is4[i]) {
-          op_rot[n] = nrot;
-          rot_seg[nrot] = seg[i];
-          rot_asc[nrot] = asc[i];
-          rot_c[nrot] = c;
-          ++nrot;
-        } else {
-          op_rot[n] = -1;
-        }
-        ++n;
-        nnode[i] = node[i] * 2;      // child 0 keeps the lower sample's slot
-        nnode[k] = node[i] * 2 + 1;  // child 1 takes the upper sample's slot
-        nis4[i] = 0;
-        nis4[k] = is4[i] ? 0 : 1;
-        nseg[i] = nseg[k] = seg[i];
-        nasc[i] = nasc[k] = asc[i];
-      }
-      for (int i = 0; i < S; ++i) {
-        node[i] = nnode[i];
-        is4[i] = nis4[i];
-        seg[i] = nseg[i];
-        asc[i] = nasc[i];
-      }
-      c /= 2;
-    }
-    for (int i = 0; i < S; ++i) {
-      slot_of_role[node[i]] = i;
-      asc_of_role[node[i]] = asc[i];
-      is4_of_role[node[i]] = is4[i];
-    }
-  }
-};
-
-// rotation constants of the DCT-IV butterflies: for instance r and sample p the pair index is
-// j = seg*M + (asc ? p : M-1-p) inside a node of n = c*M points: cos/sin((2j+1) pi / (4n)), (-1)^j
-template <int M, int L>
-struct RotTable {
-  static constexpr int NR = (RolePlan<L>::NOPS > 0 ? RolePlan<L>::NOPS : 1);
-  float c[NR][M] = {}, s[NR][M] = {};
-  constexpr RotTable() {
-    constexpr RolePlan<L> plan{};
-    for (int r = 0; r < plan.nrot; ++r)
-      for (int p = 0; p < M; ++p) {
-        const int j = plan.rot_seg[r] * M + (plan.rot_asc[r] ? p : M - 1 - p);
-        const int n = plan.rot_c[r] * M;
-        c[r][p] = float(dcts::cospi_frac(2 * j + 1, 4 * n));
-        s[r][p] = float(dcts::sinpi_frac(2 * j + 1, 4 * n));
-      }
-  }
-  // (-1)^j = sign0(r) * (-1)^p: the sign of the second rotation output needs no table
-  static constexpr float sign0(int r) {
-    constexpr RolePlan<L> plan{};
-    const int j0 = plan.rot_seg[r] * M + (plan.rot_asc[r] ? 0 : M - 1);
-    return (j0 % 2 == 0) ? 1.f : -1.f;
-  }
-};
-template <int M, int L>
-__device__ const RotTable<M, L> kRotTable{};
 
 // register budget (waves/SIMD): the role waves only hold an M-point codelet
 template <int M>
@@ -966,45 +793,6 @@ __global__ __launch_bounds__((64 << L), (split_waves_per_simd<M>())) void k_pass
                               std::make_integer_sequence<int, Cfg::ROLES>{});
 }
 
-// Workgroup barrier that orders LDS traffic only. __syncthreads() carries a workgroup-scope fence
-// over ALL address spaces: the compiler puts s_waitcnt vmcnt(0) in front of every s_barrier, i.e.
-// each barrier also waits for every direct-to-LDS load still in flight and the prefetch of the
-// next strip is drained five times per step. The data those loads bring is published by the
-// explicit s_waitcnt vmcnt(0) + barrier at the top of pass 1.
-// (A fence restricted to the "local" address space still waits vmcnt(0): the loads in flight write
-// LDS. Hence the raw instruction pair; LDS operations of a wave complete in order.)
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// Opaque copy of a lane-dependent value: everything derived from the copy has to be recomputed where
-// it is used. Without it LLVM hoists the address arithmetic of every phase (dump offsets per strip,
-// column pointers of both buffers, shuffle indices, ...) out of the persistent loop and keeps some
-// twenty loop-invariant VGPRs alive next to the parked tile: spills, and a scratch reload's
-// s_waitcnt vmcnt(0) also waits for every direct-to-LDS load in flight.
-__device__ __forceinline__ int launder(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
-// wave64 sum by DPP within rows of 16 lanes, then the four row totals in fixed order: no index
-// registers (ds_bpermute needs one per offset), result uniform across the wave
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-  auto dpp = [](float a, auto ctrl) DCTS_LAMBDA_INLINE {
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), decltype(ctrl)::value, 0xf, 0xf, true));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
-  const int b = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
-  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
-  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-  return (r0 + r1) + (r2 + r3);
-}
 
 // ---------------------------------------------------------------------------------------
 // fused split kernel: one launch, HBM traffic = the input, for tiles the register file can park
@@ -2381,7 +2169,10 @@ bool has_codelet(long long HP, long long WP) {
 
 // which single-launch large-tile kernel serves an edge: 0 none, 1 fused, 2 fused with two roles per
 // wave, 3 pipelined (AUTO order: pipelined, two-roles, fused)
+bool has_tile2d(long long N) { return N == 224; }
+
 int tile_family(int HP, int algo) {
+  if (algo == DCTS_ALGO_TILE2D) return has_tile2d(HP) ? 4 : 0;
   if (algo == DCTS_ALGO_PIPE) return has_pipe(HP) && has_fused(HP) ? 3 : 0;
   if (algo == DCTS_ALGO_AUTO && has_pipe(HP) && has_fused(HP)) return 3;
   if (has_fused2(HP) && (algo == DCTS_ALGO_FUSED || DCTS_FUSED2_AUTO)) return 2;
@@ -2390,6 +2181,8 @@ int tile_family(int HP, int algo) {
 }
 int dispatch_tile_family(int fam, int HP, const TileBatch& tb, hipStream_t st) {
   switch (fam) {
+    case 4:
+      return dctsi::dispatch_tile2d(HP, &tb, st);
     case 3:
       return dispatch_pipe(HP, tb, st);
     case 2:
@@ -2432,7 +2225,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
   if ((algo == DCTS_ALGO_CODELET || algo == DCTS_ALGO_PREFETCH) && !codelet_ok) return DCTS_E_UNSUPPORTED;
   if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET &&
-      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED && algo != DCTS_ALGO_PIPE && algo != DCTS_ALGO_LANE)
+      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED && algo != DCTS_ALGO_PIPE && algo != DCTS_ALGO_LANE && algo != DCTS_ALGO_TILE2D)
     return DCTS_E_UNSUPPORTED;
   if (algo == DCTS_ALGO_LANE && !(codelet_ok && !STORE && pad == 0 && has_lane_kernel((int)HP))) return DCTS_E_UNSUPPORTED;
   if (codelet_ok && algo != DCTS_ALGO_DIRECT) {
@@ -2464,7 +2257,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
                           strideC == H * W;
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
     const bool aligned16 = (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
-    if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE) {
+    if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) {
       const int fam = (split_ok && aligned16) ? tile_family((int)HP, algo) : 0;
       if (fam) {
         TileBatch tb;
@@ -2487,7 +2280,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       return dispatch_split((int)HP, g, out, workspace, st);
     }
   } else {
-    if (algo == DCTS_ALGO_SPLIT || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE) return DCTS_E_UNSUPPORTED;
+    if (algo == DCTS_ALGO_SPLIT || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) return DCTS_E_UNSUPPORTED;
   }
 
   const DirectWs ws = direct_ws(g.nmaps, (int)HP, (int)WP);

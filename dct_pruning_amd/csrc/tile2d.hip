@@ -1,0 +1,755 @@
+// tile2d.hip - large tiles (edge N = 8*M) as a 2-D radix-8 split: one in-register butterfly
+// pre-pass over BOTH axes, then 64 independent M x M leaf blocks.
+//
+// Replaces, for these tile shapes, the per-map loop of the reference hooks
+// (utils/common.py:262-277: dct.dct_2d(output[i,j,:,:], norm='ortho'), then sum(coeff^2)).
+//
+// Why another family. The split kernels of dct_kernels.hip transform one axis at a time: per axis
+// the strip is staged in LDS, butterflied in place (read + write), read again by the M-point role
+// codelets, and dumped once more for the other axis: 3 LDS writes + 4 reads per point and five
+// workgroup barriers per 64-column step. tools/probes/valu_probe.hip shows what that costs on
+// gfx950: a SIMD sustains one wave64 VALU instruction every 2 cycles once four waves feed it, while
+// ds_write_b32 / ds_read_b32 cost 4 / 2 cycles per CU: at 224x224 those kernels spend ~20 k cycles
+// per map in the LDS pipe and ~18 k waiting at barriers against ~13 k of VALU issue.
+//
+// Here the top three radix-2 levels of the DCT-II recursion (dct_codelets.hpp) are applied along H
+// and W at once, in registers, straight from global memory: the 8 x 8 mirrored samples
+// x[a*M + p~][b*M + q~] of an item (p, q) (p~ = p for even a, M-1-p for odd a; same for q~) go through
+// the role network of split_roles.hpp along a (rotation constants by p), then along b (by q), and
+// become one input sample of each of the 64 leaf problems Z[ra][rb] (row role ra, column role rb;
+// a leaf is a 2-D transform, DCT-II or DCT-IV of length M per axis, RoleLeaf<>::is4). The transforms
+// commute: (C_leaf o B_col) X (B_row^T o C_leaf^T) = C_leaf (B_col X B_row^T) C_leaf^T.
+// A leaf block is then transformed by one wave exactly like a small tile in k_energy_codelet:
+// lane = column, M-point codelet, transposed IN PLACE in the block's own LDS image (every lane
+// overwrites only the column it read), lane = row, second codelet, squares.
+// LDS traffic: 2 writes + 2 reads per point; workgroup barriers: 4 per map.
+//
+// One workgroup of 16 waves per CU, persistent over maps. The 64 blocks of a map go through LDS in
+// two sets of 32 (a 224 x 224 tile is 196 KiB, the LDS 160 KiB): an item's 32 outputs of the second
+// set wait in the producer's registers while the first set is transformed. The loads of the next
+// map are issued before the second set's transforms, so their latency hides there.
+//
+// As in the split family the last add/sub layer of every DCT-IV node above the leaves is folded into
+// the reduction ((a+b)^2 + (a-b)^2 = 2a^2 + 2b^2, SplitNode::wt): energy-path-only shortcut;
+// dcts_dct2d_f32_ex(DCTS_ALGO_TILE2D) stores the leaf outputs and applies that layer explicitly
+// (k_t2_tail), which is how tests compare this kernel's coefficients with the oracle.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dctscore.h"
+#include "split_roles.hpp"
+
+namespace dctsi {
+int dispatch_tile2d(int N, const void* tile_batch, hipStream_t st);
+int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, hipStream_t st);
+}  // namespace dctsi
+
+namespace {
+
+constexpr int kT2L = 3, kT2S = 8, kT2Waves = 16;
+constexpr RolePlan<kT2L> kT2Plan{};
+
+// Which two blocks a consumer wave transforms together (lanes [0, M) and [M, 2M)), per set.
+// Both blocks of a pass should run the same codelets (DCT-II or DCT-IV per axis): blocks are
+// paired inside their class (type of ra, type of rb); the class sizes are odd (25/15/15/9 for
+// L = 3), so the four left-over blocks form two passes whose second-axis codelets differ between
+// the lane halves (both run, exec-masked). Passes are sorted by cost; set 0 takes the cheaper
+// half in order, set 1 the dearer half in reverse: a wave's two passes add up evenly.
+struct T2Sched {
+  static constexpr int S = kT2S, NB = S * S, NP = NB / 2;
+  int blk[2][NP] = {};   // [set][li] -> ra * S + rb     (li = 2 * wave + lane half)
+  int set_of[NB] = {}, li_of[NB] = {};
+  constexpr T2Sched() {
+    constexpr RolePlan<kT2L> plan{};
+    int cls[4][NB] = {}, ncls[4] = {};
+    for (int ra = 0; ra < S; ++ra)
+      for (int rb = 0; rb < S; ++rb) {
+        const int c = plan.is4_of_role[ra] * 2 + plan.is4_of_role[rb];
+        cls[c][ncls[c]++] = ra * S + rb;
+      }
+    int pairs[NP][2] = {}, np = 0, single[4] = {-1, -1, -1, -1};
+    for (int c = 0; c < 4; ++c) {
+      for (int i = 0; i + 1 < ncls[c]; i += 2) {
+        pairs[np][0] = cls[c][i];
+        pairs[np][1] = cls[c][i + 1];
+        ++np;
+      }
+      if (ncls[c] % 2) single[c] = cls[c][ncls[c] - 1];
+    }
+    for (int c = 0; c < 4; c += 2)
+      if (single[c] >= 0 && single[c + 1] >= 0) {
+        pairs[np][0] = single[c];
+        pairs[np][1] = single[c + 1];
+        ++np;
+      }
+    for (int i = 0; i < NP; ++i) {
+      const int set = i < NP / 2 ? 0 : 1;
+      const int w = set == 0 ? i : NP - 1 - i;  // wave
+      for (int g = 0; g < 2; ++g) {
+        const int b = pairs[i][g];
+        blk[set][2 * w + g] = b;
+        set_of[b] = set;
+        li_of[b] = 2 * w + g;
+      }
+    }
+  }
+};
+
+constexpr T2Sched kT2Sch{};
+
+// The item slots (a, b) whose outputs belong to `set`, ordered by column slot b then a: slot i of
+// the set as a * S + b. A slot's register is free for the next map's sample once the set has been
+// written to LDS, so the next map is loaded set by set, eight slots per hook point.
+constexpr int t2_set_slot(int set, int i) {
+  int role_of_slot[kT2S] = {};
+  for (int r = 0; r < kT2S; ++r) role_of_slot[kT2Plan.slot_of_role[r]] = r;
+  int n = 0;
+  for (int b = 0; b < kT2S; ++b)
+    for (int a = 0; a < kT2S; ++a)
+      if (kT2Sch.set_of[role_of_slot[a] * kT2S + role_of_slot[b]] == set) {
+        if (n == i) return a * kT2S + b;
+        ++n;
+      }
+  return -1;
+}
+// load order of a map's 64 slots: set 0's (free first), then set 1's
+constexpr int t2_load_slot(int i) { return i < kT2S * kT2S / 2 ? t2_set_slot(0, i) : t2_set_slot(1, i - kT2S * kT2S / 2); }
+
+template <int M>
+struct T2Cfg {
+  static constexpr int L = kT2L, S = kT2S, N = M * S, NW = kT2Waves;
+  static_assert(2 * M <= 64 && 2 * M > 32, "two blocks per wave");
+  static constexpr int RS = M | 1;   // block row stride: odd, conflict-free by column and by row
+  // floats per block, == 12 (mod 32) when M = 28 so that the second block's first lanes (28..31,
+  // same half-wave as the first block's 28 lanes) land on the four banks the first block leaves free
+  static constexpr int BS = M * RS;
+  static constexpr int ZSET = (S * S / 2) * BS;       // floats: one set of 32 blocks
+  static constexpr int PI = 64 / M;                   // item rows per producer wave (2)
+  static constexpr int PWAVES = (M + PI - 1) / PI;    // producer waves (14 for M = 28)
+  static_assert(PWAVES <= NW, "producers");
+  static constexpr int NROT = 3;                      // rotations of the L = 3 network
+#ifndef DCTS_T2_HOOKS
+#define DCTS_T2_HOOKS 10, 11, 11, 10, 11, 11
+#endif
+  // next-map loads at the six hook points of a map (three per pass: before axis A, between the axes,
+  // after axis B; first the pass of set 0, then that of set 1); what is left goes out after the passes
+  static constexpr int HOOKS[6] = {DCTS_T2_HOOKS};
+  static constexpr int hook_begin(int h) {
+    int n = 0;
+    for (int i = 0; i < h; ++i) n += HOOKS[i];
+    return n;
+  }
+  static_assert(hook_begin(3) <= S * S / 2 && hook_begin(6) <= S * S, "a slot is loaded after its set has gone to LDS");
+};
+
+// rotation constants (c, s, sigma*c, sigma*s), sigma = (-1)^j of the pair index: [rot][p][4]
+template <int M>
+struct T2RotTable {
+  float v[T2Cfg<M>::NROT][M][4] = {};
+  constexpr T2RotTable() {
+    constexpr RotTable<M, kT2L> t{};
+    for (int r = 0; r < T2Cfg<M>::NROT; ++r)
+      for (int p = 0; p < M; ++p) {
+        const float sg = RotTable<M, kT2L>::sign0(r) * ((p & 1) ? -1.f : 1.f);
+        v[r][p][0] = t.c[r][p];
+        v[r][p][1] = t.s[r][p];
+        v[r][p][2] = sg * t.c[r][p];
+        v[r][p][3] = sg * t.s[r][p];
+      }
+  }
+};
+template <int M>
+__device__ const T2RotTable<M> kT2Rot{};
+
+// per (set, li): leaf types and squared amplitude weights of the block
+struct T2BlockParam {
+  int tA, tB;                    // 1: DCT-IV along p' (A) / q' (B)
+  int variant;                   // tA * 4 + tB(first block) * 2 + tB(second block) of the pass
+  float wA0, wA1, wB0, wB1;      // squared weights of output 0 / outputs > 0 per axis
+};
+template <int M>
+struct T2ParamTable {
+  T2BlockParam v[2][kT2S * kT2S / 2] = {};
+};
+template <int M, int R>
+constexpr void t2_role_weights(float& w0, float& w1) {
+  using Leaf = typename RoleLeaf<M * kT2S, kT2L, R>::type;
+  const double a = Leaf::wt(true), b = Leaf::wt(false);
+  w0 = float(a * a);
+  w1 = float(b * b);
+}
+template <int M, int... R>
+constexpr T2ParamTable<M> t2_make_params(std::integer_sequence<int, R...>) {
+  constexpr RolePlan<kT2L> plan{};
+  constexpr T2Sched sch{};
+  float w0[kT2S] = {}, w1[kT2S] = {};
+  (t2_role_weights<M, R>(w0[R], w1[R]), ...);
+  T2ParamTable<M> t{};
+  for (int s = 0; s < 2; ++s)
+    for (int li = 0; li < kT2S * kT2S / 2; ++li) {
+      const int ra = sch.blk[s][li] / kT2S, rb = sch.blk[s][li] % kT2S;
+      t.v[s][li].tA = plan.is4_of_role[ra];
+      t.v[s][li].tB = plan.is4_of_role[rb];
+      t.v[s][li].wA0 = w0[ra];
+      t.v[s][li].wA1 = w1[ra];
+      t.v[s][li].wB0 = w0[rb];
+      t.v[s][li].wB1 = w1[rb];
+    }
+  for (int s = 0; s < 2; ++s)
+    for (int li = 0; li < kT2S * kT2S / 2; li += 2)
+      t.v[s][li].variant = t.v[s][li + 1].variant = t.v[s][li].tA * 4 + t.v[s][li].tB * 2 + t.v[s][li + 1].tB;
+  return t;
+}
+template <int M>
+__device__ const T2ParamTable<M> kT2Params = t2_make_params<M>(std::make_integer_sequence<int, kT2S>{});
+
+// Diagnostic build only (-DDCTS_T2_STAMPS, tools/t2_dev.py): s_memtime stamps at the phase
+// boundaries, summed per wave into g_t2_stamps (never touches an output).
+#ifdef DCTS_T2_STAMPS
+__device__ unsigned long long g_t2_stamps[16][16];
+#define T2_STAMP(slot)                                                            \
+  do {                                                                            \
+    unsigned long long t_;                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    acc_[slot] += t_ - last_;                                                     \
+    last_ = t_;                                                                   \
+  } while (0)
+#else
+#define T2_STAMP(slot) ((void)0)
+#endif
+
+// the L = 3 role network on 8 values held in registers: y[slot], constants by lane
+template <int M>
+__device__ __forceinline__ void t2_network(float (&y)[kT2S], const float (&rc)[T2Cfg<M>::NROT][4]) {
+  constexpr RolePlan<kT2L> plan{};
+  dcts::static_for<plan.NOPS>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int o = decltype(i)::value;
+    constexpr int a = plan.op_a[o], b = plan.op_b[o], r = plan.op_rot[o];
+    const float ya = y[a], yb = y[b];
+    if constexpr (r < 0) {
+      y[a] = ya + yb;
+      y[b] = ya - yb;
+    } else {
+      y[a] = ya * rc[r][0] + yb * rc[r][1];
+      y[b] = yb * rc[r][2] - ya * rc[r][3];
+    }
+  });
+}
+
+// Leaf transforms in stages, with scheduling barriers between the half-size sub-transforms and the
+// outputs handed to `sink(k, value)` as soon as a stage has them (an LDS store on axis A, a square on
+// axis B). Left to itself the machine scheduler interleaves the independent halves of a codelet for
+// ILP until it runs into the 128-VGPR limit, and the register allocator then spills a handful of the
+// caller's long-lived values (the parked outputs, the next map's samples) around every codelet. One
+// wave issues a VALU instruction every ~8 cycles whatever the ILP (tools/probes/valu_probe.hip), so
+// the narrow schedule costs nothing. Same arithmetic as dcts::Dct2 / dcts::Dct4, bit for bit.
+template <int M, class Sink>
+__device__ __forceinline__ void t2_dct2_staged(const float (&x)[M], Sink sink) {
+  static_assert(M % 2 == 0, "even leaf");
+  constexpr int H = M / 2;
+  float u[H], v[H];
+  dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int n = decltype(i)::value;
+    u[n] = x[n] + x[M - 1 - n];
+    v[n] = x[n] - x[M - 1 - n];
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float E[H];
+    dcts::Dct2<H>::run(u, E);
+    dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE { sink(std::integral_constant<int, 2 * decltype(i)::value>{}, E[decltype(i)::value]); });
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float O[H];
+    dcts::Dct4<H>::run(v, O);
+    dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE { sink(std::integral_constant<int, 2 * decltype(i)::value + 1>{}, O[decltype(i)::value]); });
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int M, class Sink>
+__device__ __forceinline__ void t2_dct4_staged(const float (&v)[M], Sink sink) {
+  static_assert(M % 2 == 0, "even leaf");
+  constexpr int H = M / 2;
+  float a[H], b[H];
+  dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int n = decltype(i)::value;
+    constexpr float c = float(dcts::cospi_frac(2 * n + 1, 4 * M));
+    constexpr float sn = float(dcts::sinpi_frac(2 * n + 1, 4 * M));
+    constexpr float sg = (n % 2 == 0) ? 1.0f : -1.0f;
+    a[n] = v[n] * c + v[M - 1 - n] * sn;
+    b[n] = v[M - 1 - n] * (sg * c) - v[n] * (sg * sn);
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  float A[H], B[H];
+  dcts::Dct2<H>::run(a, A);
+  __builtin_amdgcn_sched_barrier(0);
+  dcts::Dct2<H>::run(b, B);
+  __builtin_amdgcn_sched_barrier(0);
+  sink(std::integral_constant<int, 0>{}, A[0]);
+  sink(std::integral_constant<int, M - 1>{}, -B[0]);
+  dcts::static_for<H - 1>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int jj = decltype(i)::value + 1;
+    sink(std::integral_constant<int, 2 * jj>{}, A[jj] + B[H - jj]);
+    sink(std::integral_constant<int, 2 * jj - 1>{}, A[jj] - B[H - jj]);
+  });
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One pass = two leaf blocks (lane halves). Each axis is straight-line code per codelet type, picked
+// by a wave-uniform branch AROUND the whole axis (stores / squares inside the arms): a branch between
+// the DCT-II and the DCT-IV codelet with the 28 outputs merged behind it doubled the footprint
+// (41 -> 80 VGPRs) and spilled next to the parked values, and a scratch reload waits vmcnt(0), i.e. for
+// the prefetch of the next map. The next map's loads are issued BETWEEN the axes, outside every arm
+// (inside, each arm would define the 64 sample registers and the merge again costs registers).
+template <int M>
+struct T2Pass {
+  lds_ptr blk;
+  lds_cptr pp;
+  int g, j, li;
+  bool act;
+  __device__ __forceinline__ T2Pass(lds_ptr zbuf, lds_cptr params, int set, int wave, int lane) {
+    g = lane >= M ? 1 : 0;
+    j = lane - g * M;
+    act = lane < 2 * M;
+    li = 2 * wave + g;
+    pp = params + (set * (kT2S * kT2S / 2) + li) * 8;
+    blk = zbuf + li * T2Cfg<M>::BS;
+  }
+};
+
+// axis A: lane = column q', transform along p', in place in the block's LDS image
+template <int M, int TA>
+__device__ __forceinline__ void t2_axis_a(const T2Pass<M>& ps) {
+  constexpr int RS = T2Cfg<M>::RS;
+  float in[M];
+  lds_cptr src = ps.blk + (ps.act ? ps.j : 0);
+  dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { in[decltype(i)::value] = src[decltype(i)::value * RS]; });
+  // this lane's own column. Unconditional stores (idle lanes hit the pad column M < RS, which nobody
+  // reads): an exec-masked store block kept all M outputs alive at once, 62 VGPRs instead of 44
+  lds_ptr dst = ps.blk + (ps.act ? ps.j : M);
+  auto put = [&](auto k, float val) DCTS_LAMBDA_INLINE { dst[decltype(k)::value * RS] = val; };
+  if constexpr (TA)
+    t2_dct4_staged<M>(in, put);
+  else
+    t2_dct2_staged<M>(in, put);
+}
+
+// axis B: lane = row k1, transform along q'; returns the lane's weighted energy. A mixed pass (the
+// lane halves differ in type) runs both codelets on every lane, one after the other (the row is read
+// twice), and keeps the sums of the lane's own type: straight-line, same footprint as the others.
+template <int M, int TB0, int TB1, bool STORE>
+__device__ __forceinline__ float t2_axis_b(const T2Pass<M>& ps, int set, float* leaf_out) {
+  constexpr int RS = T2Cfg<M>::RS;
+  float s0 = 0.f, s1 = 0.f;
+  auto run = [&](auto tb, bool mine) DCTS_LAMBDA_INLINE {
+    constexpr int TB = decltype(tb)::value;
+    float z[M];
+    lds_cptr src = ps.blk + (ps.act ? ps.j : 0) * RS;
+    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { z[decltype(i)::value] = src[decltype(i)::value]; });
+    float t0 = 0.f, t1 = 0.f;
+    // debug / parity path: leaf outputs, unweighted, as [set * 32 + li][k1][k2]
+    float* o = STORE ? leaf_out + ((long long)(set * (kT2S * kT2S / 2) + ps.li) * M + ps.j) * M : nullptr;
+    auto sq = [&](auto k, float val) DCTS_LAMBDA_INLINE {
+      if constexpr (decltype(k)::value == 0)
+        t0 = val * val;
+      else
+        t1 = fmaf(val, val, t1);
+      if constexpr (STORE) {
+        if (ps.act && mine) o[decltype(k)::value] = val;
+      }
+    };
+    if constexpr (TB)
+      t2_dct4_staged<M>(z, sq);
+    else
+      t2_dct2_staged<M>(z, sq);
+    s0 = mine ? t0 : s0;
+    s1 = mine ? t1 : s1;
+  };
+  if constexpr (TB0 == TB1) {
+    run(std::integral_constant<int, TB0>{}, true);
+  } else {
+    run(std::integral_constant<int, TB0>{}, ps.g == 0);
+    asm volatile("" ::: "memory");
+    run(std::integral_constant<int, TB1>{}, ps.g != 0);
+  }
+  const float e = (ps.j == 0 ? ps.pp[2] : ps.pp[3]) * (ps.pp[4] * s0 + ps.pp[5] * s1);
+  return ps.act ? e : 0.f;
+}
+
+// variant id of a pass: TA * 4 + TB0 * 2 + TB1; which ones occur in a set is known at compile time
+constexpr int t2_variant(int set, int w) {
+  const int b0 = kT2Sch.blk[set][2 * w], b1 = kT2Sch.blk[set][2 * w + 1];
+  const int ta = kT2Plan.is4_of_role[b0 / kT2S];  // == that of b1 (pairs share axis A's type)
+  return ta * 4 + kT2Plan.is4_of_role[b0 % kT2S] * 2 + kT2Plan.is4_of_role[b1 % kT2S];
+}
+// does a pass of `set` have (variant & mask) == value?
+constexpr bool t2_set_has(int set, int mask, int value) {
+  for (int w = 0; w < kT2Waves; ++w)
+    if ((t2_variant(set, w) & mask) == value) return true;
+  return false;
+}
+static_assert([] {
+  for (int s = 0; s < 2; ++s)
+    for (int w = 0; w < kT2Waves; ++w)
+      if (kT2Plan.is4_of_role[kT2Sch.blk[s][2 * w] / kT2S] != kT2Plan.is4_of_role[kT2Sch.blk[s][2 * w + 1] / kT2S]) return false;
+  return true;
+}(), "the two blocks of a pass share the type of axis A");
+
+// exhaustive if / else chains over the types a set contains (the last one is the else arm)
+template <int M, int SET>
+__device__ __forceinline__ void t2_axis_a_chain(int vid, const T2Pass<M>& ps) {
+  constexpr bool has0 = t2_set_has(SET, 4, 0), has1 = t2_set_has(SET, 4, 4);
+  if constexpr (has0 && has1) {
+    if (vid & 4)
+      t2_axis_a<M, 1>(ps);
+    else
+      t2_axis_a<M, 0>(ps);
+  } else if constexpr (has1) {
+    t2_axis_a<M, 1>(ps);
+  } else {
+    t2_axis_a<M, 0>(ps);
+  }
+}
+template <int M, int SET, bool STORE, int TB>
+__device__ __forceinline__ float t2_axis_b_chain(int vid, const T2Pass<M>& ps, float* leaf_out) {
+  constexpr bool here = t2_set_has(SET, 3, TB);
+  constexpr bool later = [] {
+    for (int u = TB + 1; u < 4; ++u)
+      if (t2_set_has(SET, 3, u)) return true;
+    return false;
+  }();
+  if constexpr (here && later) {
+    if ((vid & 3) == TB) return t2_axis_b<M, (TB >> 1) & 1, TB & 1, STORE>(ps, SET, leaf_out);
+    return t2_axis_b_chain<M, SET, STORE, TB + 1>(vid, ps, leaf_out);
+  } else if constexpr (here) {
+    return t2_axis_b<M, (TB >> 1) & 1, TB & 1, STORE>(ps, SET, leaf_out);
+  } else {
+    static_assert(TB < 3, "a set has at least one variant");
+    return t2_axis_b_chain<M, SET, STORE, TB + 1>(vid, ps, leaf_out);
+  }
+}
+
+// One pass with the caller's hook at three points: before axis A, between the axes, after axis B.
+// The caller trickles the next map's loads out there: a burst of loads blocks the issuing wave until
+// the CU's miss queue has room (stamps: 10 k cycles per map for 32 loads per wave in one go, i.e. the
+// HBM rate); spread over the transforms they do not queue up.
+template <int M, int SET, bool STORE, class Hook>
+__device__ __forceinline__ float t2_consume(int vid, lds_ptr zbuf, lds_cptr params, int wave, int lane, float* leaf_out, Hook hook) {
+  const T2Pass<M> ps(zbuf, params, SET, wave, lane);
+  hook(std::integral_constant<int, 0>{});
+  __builtin_amdgcn_sched_barrier(0);
+  t2_axis_a_chain<M, SET>(vid, ps);
+  __builtin_amdgcn_sched_barrier(0);
+  hook(std::integral_constant<int, 1>{});
+  __builtin_amdgcn_sched_barrier(0);
+  // the wave's own LDS traffic is in order; only the compiler must not reorder
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float e = t2_axis_b_chain<M, SET, STORE, 0>(vid, ps, leaf_out);
+  asm volatile("" : "+v"(e));
+  __builtin_amdgcn_sched_barrier(0);
+  hook(std::integral_constant<int, 2>{});
+  __builtin_amdgcn_sched_barrier(0);
+  return e;
+}
+
+// issue the loads of item (p, q) of a map for the column slots b in [B0, B1): buffer loads (one
+// wave-uniform descriptor per map, four lane offsets, the slot's offset as the scalar/immediate part)
+// instead of 64 per-lane 64-bit addresses; out-of-range reads return 0
+template <int M, int B0, int B1>
+__device__ __forceinline__ void t2_load(const float* __restrict__ in_b, int p, int q, float (&v)[kT2S][kT2S]) {
+  constexpr int N = T2Cfg<M>::N;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, N * N * 4, 0x00020000);
+  const int pe = p, po = M - 1 - p, qe = q, qo = M - 1 - q;
+  const int o_ee = (pe * N + qe) * 4, o_eo = (pe * N + qo) * 4, o_oe = (po * N + qe) * 4, o_oo = (po * N + qo) * 4;
+  dcts::static_for<kT2S>([&](auto ia) DCTS_LAMBDA_INLINE {
+    constexpr int a = decltype(ia)::value;
+    dcts::static_for<B1 - B0>([&](auto ib) DCTS_LAMBDA_INLINE {
+      constexpr int b = B0 + decltype(ib)::value;
+      const int voff = (a % 2 == 0) ? ((b % 2 == 0) ? o_ee : o_eo) : ((b % 2 == 0) ? o_oe : o_oo);
+      v[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (a * M * N + b * M) * 4, 0));
+    });
+  });
+}
+
+// the same for entries [I0, I1) of the load order (t2_load_slot)
+template <int M, int I0, int I1>
+__device__ __forceinline__ void t2_load_seq(const float* __restrict__ in_b, int p, int q, float (&v)[kT2S][kT2S]) {
+  constexpr int N = T2Cfg<M>::N;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, N * N * 4, 0x00020000);
+  const int pe = p, po = M - 1 - p, qe = q, qo = M - 1 - q;
+  const int o_ee = (pe * N + qe) * 4, o_eo = (pe * N + qo) * 4, o_oe = (po * N + qe) * 4, o_oo = (po * N + qo) * 4;
+  dcts::static_for<(I1 > I0 ? I1 - I0 : 0)>([&](auto ii) DCTS_LAMBDA_INLINE {
+    constexpr int sl = t2_load_slot(I0 + decltype(ii)::value);
+    static_assert(sl >= 0, "slot");
+    constexpr int a = sl / kT2S, b = sl % kT2S;
+    const int voff = (a % 2 == 0) ? ((b % 2 == 0) ? o_ee : o_eo) : ((b % 2 == 0) ? o_oe : o_oo);
+    v[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (a * M * N + b * M) * 4, 0));
+  });
+}
+
+template <int M, class Src, bool STORE>
+__device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot, lds_ptr params, lds_ptr partials,
+                                        float* leaf_out) {
+  using Cfg = T2Cfg<M>;
+  constexpr int S = kT2S, RS = Cfg::RS, BS = Cfg::BS, NROT = Cfg::NROT;
+  const int lane_in = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef DCTS_T2_STAMPS
+  unsigned long long acc_[16] = {}, last_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
+  // tables -> LDS (read per map instead of living in registers)
+  for (int i = threadIdx.x; i < NROT * M * 4; i += blockDim.x) rot[i] = (&kT2Rot<M>.v[0][0][0])[i];
+  for (int i = threadIdx.x; i < 2 * (S * S / 2); i += blockDim.x) {
+    const T2BlockParam& bp = (&kT2Params<M>.v[0][0])[i];
+    params[i * 8 + 0] = __builtin_bit_cast(float, bp.tA);
+    params[i * 8 + 1] = __builtin_bit_cast(float, bp.tB);
+    params[i * 8 + 2] = bp.wA0;
+    params[i * 8 + 3] = bp.wA1;
+    params[i * 8 + 4] = bp.wB0;
+    params[i * 8 + 5] = bp.wB1;
+    params[i * 8 + 6] = __builtin_bit_cast(float, bp.variant);
+  }
+  const bool producer = wave < Cfg::PWAVES;
+  const long long nmaps = tb.total;
+  long long m = blockIdx.x;
+  long long pending_m = -1;
+  int pslot = 0, pending_slot = 0;
+  float v[S][S];
+  auto item_pq = [&](int& p, int& q, bool& ok) DCTS_LAMBDA_INLINE {
+    const int lane = launder(lane_in);
+    const int pi = lane >= M ? 1 : 0;
+    q = lane - pi * M;
+    p = Cfg::PI * wave + pi;
+    ok = lane < Cfg::PI * M && p < M;
+    if (!ok) {
+      p = 0;
+      q = 0;
+    }
+  };
+  {
+    // every wave loads and butterflies (the two waves without items redo item 0 and store nothing):
+    // a conditional load would merge with the OLD values behind it and keep all 64 of them alive
+    // across the transforms - that merge, not the prefetch, was what spilled
+    int p, q;
+    bool ok;
+    item_pq(p, q, ok);
+    t2_load<M, 0, S>(tile_in(tb, m), p, q, v);  // grid <= nmaps: every workgroup owns a map
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  auto finish = [&]() DCTS_LAMBDA_INLINE {
+    if (pending_m >= 0) {
+      if (wave == 0 && lane_in == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < kT2Waves; ++i) t += partials[pending_slot * kT2Waves + i];
+        constexpr float sc = float(4.0 / (double(Cfg::N) * double(Cfg::N)));
+        *tile_out(tb, pending_m) = t * sc;
+      }
+      pending_m = -1;
+    }
+  };
+  lds_barrier();  // tables are in LDS
+  T2_STAMP(15);
+  for (; m < nmaps; m += gridDim.x) {
+    // ---- A: butterflies of this wave's items, both axes, in registers ---------------------------
+    {
+      int p, q;
+      bool ok;
+      item_pq(p, q, ok);
+      float rp[NROT][4];
+      dcts::static_for<NROT>([&](auto ir) DCTS_LAMBDA_INLINE {
+        constexpr int r = decltype(ir)::value;
+        dcts::static_for<4>([&](auto ic) DCTS_LAMBDA_INLINE { rp[r][decltype(ic)::value] = rot[(r * M + p) * 4 + decltype(ic)::value]; });
+      });
+      // along a (the H axis) for every b: constants by p
+      dcts::static_for<S>([&](auto ib) DCTS_LAMBDA_INLINE {
+        constexpr int b = decltype(ib)::value;
+        float y[S];
+        dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE { y[decltype(ia)::value] = v[decltype(ia)::value][b]; });
+        t2_network<M>(y, rp);
+        dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE { v[decltype(ia)::value][b] = y[decltype(ia)::value]; });
+        // one network at a time: interleaved for ILP the eight of them run the registers out, and what
+        // the allocator then spills are the long-lived samples / parked outputs
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      float rq[NROT][4];
+      dcts::static_for<NROT>([&](auto ir) DCTS_LAMBDA_INLINE {
+        constexpr int r = decltype(ir)::value;
+        dcts::static_for<4>([&](auto ic) DCTS_LAMBDA_INLINE { rq[r][decltype(ic)::value] = rot[(r * M + q) * 4 + decltype(ic)::value]; });
+      });
+      // along b (the W axis) for every a: constants by q
+      dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE {
+        constexpr int a = decltype(ia)::value;
+        t2_network<M>(v[a], rq);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    T2_STAMP(0);
+    lds_barrier();  // #4 of the previous map: every consumer is done with set 1 in zbuf
+    T2_STAMP(1);
+    finish();
+    auto write_set = [&](auto iset) DCTS_LAMBDA_INLINE {
+      constexpr int SET = decltype(iset)::value;
+      int p, q;
+      bool ok;
+      item_pq(p, q, ok);
+      {
+        // lanes without an item store into the pad column (q' = M < RS), unconditionally: see t2_consume
+        const int qa = ok ? q : M, qd = ok ? M - 1 - q : M;
+        const int o_aa = p * RS + qa, o_ad = p * RS + qd, o_da = (M - 1 - p) * RS + qa, o_dd = (M - 1 - p) * RS + qd;
+        dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE {
+          constexpr int ra = decltype(ia)::value;
+          dcts::static_for<S>([&](auto ib) DCTS_LAMBDA_INLINE {
+            constexpr int rb = decltype(ib)::value;
+            constexpr int bid = ra * S + rb;
+            if constexpr (kT2Sch.set_of[bid] == SET) {
+              constexpr int a = kT2Plan.slot_of_role[ra], b = kT2Plan.slot_of_role[rb];
+              constexpr bool asc_a = kT2Plan.asc_of_role[ra] != 0, asc_b = kT2Plan.asc_of_role[rb] != 0;
+              const int off = asc_a ? (asc_b ? o_aa : o_ad) : (asc_b ? o_da : o_dd);
+              zbuf[kT2Sch.li_of[bid] * BS + off] = v[a][b];
+            }
+          });
+        });
+      }
+    };
+    if (producer) write_set(std::integral_constant<int, 0>{});
+    T2_STAMP(2);
+    lds_barrier();  // #1
+    T2_STAMP(3);
+    float* lo = leaf_out ? leaf_out + m * (long long)Cfg::N * Cfg::N : nullptr;
+    const int vid0 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, params[(0 * (S * S / 2) + 2 * wave) * 8 + 6]));
+    const int vid1 = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, params[(1 * (S * S / 2) + 2 * wave) * 8 + 6]));
+    // The next map's 64 loads per lane are trickled out during the transforms of BOTH sets, eight
+    // per hook point, straight into the registers of this map's outputs that have just gone to
+    // LDS: the slots of set 0 while set 0 is transformed, those of set 1 during set 1 (in column
+    // order: phase A runs its H-axis networks column by column, which covers what is left of the
+    // last loads' latency). 32 parked + 32 landing + 44 for a pass fit the 128 VGPRs of a 16-wave
+    // workgroup; so do 64 landing + 44.
+    const bool more = m + gridDim.x < nmaps;
+    const float* nsrc = tile_in(tb, more ? m + gridDim.x : m);  // last map: reload it (unused), see above
+    auto trickle = [&](auto set) DCTS_LAMBDA_INLINE {
+      return [&](auto k) DCTS_LAMBDA_INLINE {
+        constexpr int h = 3 * decltype(set)::value + decltype(k)::value;
+        constexpr int i0 = Cfg::hook_begin(h), n = Cfg::HOOKS[h];
+        if constexpr (n > 0) {
+          int p, q;
+          bool ok;
+          item_pq(p, q, ok);
+          t2_load_seq<M, i0, i0 + n>(nsrc, p, q, v);
+        }
+      };
+    };
+    float e = t2_consume<M, 0, STORE>(vid0, zbuf, params, wave, launder(lane_in), lo, trickle(std::integral_constant<int, 0>{}));
+    asm volatile("" : "+v"(e));
+    T2_STAMP(4);
+    lds_barrier();  // #2
+    T2_STAMP(5);
+    if (producer) write_set(std::integral_constant<int, 1>{});
+    T2_STAMP(6);
+    lds_barrier();  // #3
+    T2_STAMP(7);
+    T2_STAMP(8);
+    e += t2_consume<M, 1, STORE>(vid1, zbuf, params, wave, launder(lane_in), lo, trickle(std::integral_constant<int, 1>{}));
+    asm volatile("" : "+v"(e));
+    T2_STAMP(9);
+    if constexpr (Cfg::hook_begin(6) < S * S) {
+      asm volatile("" ::: "memory");
+      int p, q;
+      bool ok;
+      item_pq(p, q, ok);
+      t2_load_seq<M, Cfg::hook_begin(6), S * S>(nsrc, p, q, v);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    e = wave_sum_dpp(e);
+    if (lane_in == 0) partials[pslot * kT2Waves + wave] = e;
+    pending_m = m;
+    pending_slot = pslot;
+    pslot ^= 1;
+    T2_STAMP(10);
+  }
+  lds_barrier();
+  finish();
+#ifdef DCTS_T2_STAMPS
+  if (lane_in == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_t2_stamps[wave][i], acc_[i]);
+#endif
+}
+
+template <int M, bool STORE>
+__global__ __launch_bounds__(64 * kT2Waves) void k_tile2d(TileBatch tb, float* leaf_out) {
+  using Cfg = T2Cfg<M>;
+  __shared__ __attribute__((aligned(16))) float zbuf[Cfg::ZSET];
+  __shared__ __attribute__((aligned(16))) float rot[Cfg::NROT * M * 4];
+  __shared__ __attribute__((aligned(16))) float params[2 * (kT2S * kT2S / 2) * 8];
+  __shared__ float partials[2 * kT2Waves];
+  t2_body<M, TileBatch, STORE>(tb, (lds_ptr)zbuf, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
+}
+
+#define DCTS_TILE2D_TABLE(X) X(224, 28)
+
+template <int M>
+int launch_tile2d(const TileBatch& tb, hipStream_t st) {
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+      n = 256;
+    return n;
+  }();
+  const long long grid = tb.total < ncu ? tb.total : ncu;  // LDS: one workgroup per CU
+  hipLaunchKernelGGL((k_tile2d<M, false>), dim3((unsigned)grid), dim3(64 * kT2Waves), 0, st, tb, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+#ifdef DCTS_T2_DEV
+// development entry points (tools/t2_dev.py builds this file alone: seconds instead of minutes)
+extern "C" int t2_dev_run(const float* x, long long nmaps, int edge, float* out, void* stream) {
+  TileBatch tb;
+  for (int i = 0; i < kTileItems; ++i) {
+    tb.x[i] = x;
+    tb.out[i] = out;
+    tb.begin[i] = 0;
+  }
+  tb.begin[1] = tb.begin[kTileItems] = nmaps;
+  tb.map_elems = (long long)edge * edge;
+  tb.total = nmaps;
+  tb.count = 1;
+  return dctsi::dispatch_tile2d(edge, &tb, reinterpret_cast<hipStream_t>(stream));
+}
+#ifdef DCTS_T2_STAMPS
+extern "C" int t2_dev_stamps(unsigned long long* host_out /*[16][16]*/, int reset) {
+  if (reset) {
+    static unsigned long long zeros[16][16] = {};
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_t2_stamps), zeros, sizeof(zeros));
+  }
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_t2_stamps), 16 * 16 * sizeof(unsigned long long));
+}
+#endif
+#endif
+
+namespace dctsi {
+int dispatch_tile2d(int N, const void* tile_batch, hipStream_t st) {
+  const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
+#define DCTS_CASE(N_, M_) \
+  case N_:                \
+    return launch_tile2d<M_>(tb, st);
+  switch (N) {
+    DCTS_TILE2D_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, hipStream_t st) {
+  return DCTS_E_UNSUPPORTED;
+}
+}  // namespace dctsi

@@ -63,7 +63,9 @@ enum {
                              (edges 72 ... 256; 288 and 320 with two roles per wave)             */
   DCTS_ALGO_PIPE = 6,     /* the fused kernel software-pipelined: pass 2 of one map interleaved
                              with pass 1 of the next                                             */
-  DCTS_ALGO_LANE = 7      /* one lane per map, both passes in registers (7x7, 9x9)              */
+  DCTS_ALGO_LANE = 7,     /* one lane per map, both passes in registers (7x7, 9x9)              */
+  DCTS_ALGO_TILE2D = 8    /* edge 8*M: radix-8 butterflies over both axes in registers, then 64
+                             independent M x M leaf blocks (tile2d.hip)                          */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */
