@@ -147,7 +147,9 @@ def kernel_name(edge, per_tensor):
         return "k_energy_lane_multi<%d>" % edge
     if edge <= 64:
         return ("k_energy_codelet<%d,%d>" if per_tensor else "k_energy_codelet_multi<%d,%d>") % (edge, edge)
-    if edge in (128, 224):
+    if edge == 224:
+        return "k_tile2d (224x224)"
+    if edge == 128:
         return "k_split_pipe (%dx%d)" % (edge, edge)
     if edge in (288, 320):
         return "k_split_fused2 (%dx%d)" % (edge, edge)

@@ -51,6 +51,11 @@ int dispatch_fused(int N, const void* tile_batch, hipStream_t st);
 int dispatch_fused2(int N, const void* tile_batch, hipStream_t st);
 int dispatch_pipe(int N, const void* tile_batch, hipStream_t st);
 int dispatch_tile2d(int N, const void* tile_batch, hipStream_t st);  // tile2d.hip
+// coefficient output through the large-tile kernels (debug / parity): leaf outputs into `scratch`
+// (scratch_maps tiles), then k_assemble
+int dispatch_fused_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
+int dispatch_fused2_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
+int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
 }  // namespace dctsi
 
 namespace {
@@ -893,8 +898,12 @@ __device__ __forceinline__ void fused_finish(lds_ptr partials, int slot, long lo
   }
 }
 
-template <int M, int L, int ROLE>
-__device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds_ptr partials, int lane) {
+// STORE: debug / parity instantiation (dcts_dct2d_f32_ex with DCTS_ALGO_FUSED): the weighted leaf outputs
+// of pass 2 also go to leaf_out[map][roleH * M + kH][roleW * M + kW]; k_assemble (split_roles.hpp) applies
+// the DCT-IV add/sub layers the energy path folds into its weights. No energy is written.
+template <int M, int L, int ROLE, bool STORE = false>
+__device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds_ptr partials, int lane,
+                                           float* leaf_out = nullptr) {
   using Cfg = FusedCfg<M, L>;
   constexpr int N = Cfg::N, S = Cfg::S, SW = Cfg::SW, STRIPS = Cfg::STRIPS, COLS = Cfg::COLS, KPR = Cfg::KPR,
                 RPR = Cfg::RPR, ROUNDS = Cfg::ROUNDS, RW = Cfg::RW, BUF = Cfg::BUF;
@@ -923,7 +932,7 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
       lds_barrier();                                   // ... for everyone; the other buffer is free
       if constexpr (s == 0) {
         if (pending_m >= 0) {
-          fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
+          if constexpr (!STORE) fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
           pending_m = -1;
         }
       }
@@ -997,6 +1006,21 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
       DCTS_STAMP(10);
       float o[M];
       split_role_transform<M, L, ROLE>(blk + (act ? lane : 0), RW, o);
+      if constexpr (STORE) {
+        // image column `lane` of round r holds the H-axis leaf output iH
+        int iH;
+        if constexpr (Cfg::BALANCED) {
+          const int q = lane / KPR, kh = r * KPR + (lane - q * KPR);
+          iH = kh < M ? q * M + kh : -1;  // padding columns
+        } else {
+          const int q = lane / M;
+          iH = (r * RPR + q) * M + (lane - q * M);
+        }
+        if (act && iH >= 0) {
+          float* dst = leaf_out + ((long long)m * N + iH) * N + ROLE * M;
+          dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE { dst[decltype(ik)::value] = o[decltype(ik)::value]; });
+        }
+      }
       float er = 0.f;
       dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
         constexpr int k = decltype(ik)::value;
@@ -1018,7 +1042,7 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
   }
   if (pending_m >= 0) {
     lds_barrier();
-    fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
+    if constexpr (!STORE) fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
   }
 #ifdef DCTS_FUSED_STAMPS
   if (lane == 0)
@@ -1026,10 +1050,10 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
 #endif
 }
 
-template <int M, int L, int... R>
+template <int M, int L, bool STORE, int... R>
 __device__ __forceinline__ void fused_dispatch(int role, const TileBatch& tb, lds_ptr lds, lds_ptr partials, int lane,
-                                               std::integer_sequence<int, R...>) {
-  ((role == R ? fused_body<M, L, R>(tb, lds, partials, lane) : (void)0), ...);
+                                               float* leaf_out, std::integer_sequence<int, R...>) {
+  ((role == R ? fused_body<M, L, R, STORE>(tb, lds, partials, lane, leaf_out) : (void)0), ...);
 }
 
 // waves per SIMD the register file allows: STRIPS*M parked values + the codelet's working set
@@ -1048,8 +1072,16 @@ __global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_s
   using Cfg = FusedCfg<M, L>;
   __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF];
   __shared__ float partials[2 * Cfg::S];
-  fused_dispatch<M, L>(threadIdx.x >> 6, tb, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63,
-                       std::make_integer_sequence<int, Cfg::S>{});
+  fused_dispatch<M, L, false>(threadIdx.x >> 6, tb, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63, nullptr,
+                              std::make_integer_sequence<int, Cfg::S>{});
+}
+template <int M, int L>
+__global__ __launch_bounds__((64 << L), (fused_waves_per_simd<M, L>())) void k_split_fused_coeff(TileBatch tb, float* leaf_out) {
+  using Cfg = FusedCfg<M, L>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * Cfg::BUF];
+  __shared__ float partials[2 * Cfg::S];
+  fused_dispatch<M, L, true>(threadIdx.x >> 6, tb, (lds_ptr)lds, (lds_ptr)partials, threadIdx.x & 63, leaf_out,
+                             std::make_integer_sequence<int, Cfg::S>{});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1083,9 +1115,9 @@ struct Fused2Cfg {
   static_assert(2 * BUF <= LDS_FLOATS, "LDS");
 };
 
-template <int M, int L, int W>
+template <int M, int L, int W, bool STORE = false>
 __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, lds_ptr buf1, lds_ptr partials,
-                                            int lane_in) {
+                                            int lane_in, float* leaf_out = nullptr) {
   using Cfg = Fused2Cfg<M, L>;
   using Stage = FusedStage<M, L, Cfg::NW>;
   constexpr int N = Cfg::N, NW = Cfg::NW, SW = Cfg::SW, STRIPS = Cfg::STRIPS, KPR = Cfg::KPR,
@@ -1101,7 +1133,7 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
 #pragma unroll
       for (int i = 0; i < NW; ++i) t += part[slot * NW + i];
       constexpr float sc = float(4.0 / (double(N) * double(N)));
-      *tile_out(tb, mm) = t * sc;
+      if constexpr (!STORE) *tile_out(tb, mm) = t * sc;
     }
   };
   if (m < nmaps) {
@@ -1187,6 +1219,13 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
         const int ln = launder(lane_in);
         float o[M];
         split_role_transform<M, L, 2 * W + i>(blk + (ln < COLS ? ln : 0), RW, o);
+        if constexpr (STORE) {  // see fused_body
+          const int q = ln / KPR, kh = r * KPR + (ln - q * KPR);
+          if (ln < COLS && kh < M) {
+            float* dst = leaf_out + ((long long)m * N + q * M + kh) * N + (2 * W + i) * M;
+            dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE { dst[decltype(ik)::value] = o[decltype(ik)::value]; });
+          }
+        }
         float er = 0.f;
         dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
           constexpr int k = decltype(ik)::value;
@@ -1218,10 +1257,11 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
   }
 }
 
-template <int M, int L, int... Wv>
+template <int M, int L, bool STORE, int... Wv>
 __device__ __forceinline__ void fused2_dispatch(int wave, const TileBatch& tb, lds_ptr buf0, lds_ptr buf1,
-                                                lds_ptr partials, int lane, std::integer_sequence<int, Wv...>) {
-  ((wave == Wv ? fused2_body<M, L, Wv>(tb, buf0, buf1, partials, lane) : (void)0), ...);
+                                                lds_ptr partials, int lane, float* leaf_out,
+                                                std::integer_sequence<int, Wv...>) {
+  ((wave == Wv ? fused2_body<M, L, Wv, STORE>(tb, buf0, buf1, partials, lane, leaf_out) : (void)0), ...);
 }
 
 template <int M, int L>
@@ -1230,8 +1270,17 @@ __global__ __launch_bounds__((64 * Fused2Cfg<M, L>::NW), 2) void k_split_fused2(
   __shared__ __attribute__((aligned(16))) float buf0[Cfg::BUF];
   __shared__ __attribute__((aligned(16))) float buf1[Cfg::BUF];
   __shared__ float partials[Cfg::DEFER ? 2 * Cfg::NW : 1];
-  fused2_dispatch<M, L>(threadIdx.x >> 6, tb, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)partials, threadIdx.x & 63,
-                        std::make_integer_sequence<int, Cfg::NW>{});
+  fused2_dispatch<M, L, false>(threadIdx.x >> 6, tb, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)partials, threadIdx.x & 63,
+                               nullptr, std::make_integer_sequence<int, Cfg::NW>{});
+}
+template <int M, int L>
+__global__ __launch_bounds__((64 * Fused2Cfg<M, L>::NW), 2) void k_split_fused2_coeff(TileBatch tb, float* leaf_out) {
+  using Cfg = Fused2Cfg<M, L>;
+  __shared__ __attribute__((aligned(16))) float buf0[Cfg::BUF];
+  __shared__ __attribute__((aligned(16))) float buf1[Cfg::BUF];
+  __shared__ float partials[Cfg::DEFER ? 2 * Cfg::NW : 1];
+  fused2_dispatch<M, L, true>(threadIdx.x >> 6, tb, (lds_ptr)buf0, (lds_ptr)buf1, (lds_ptr)partials, threadIdx.x & 63,
+                              leaf_out, std::make_integer_sequence<int, Cfg::NW>{});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1701,7 +1750,17 @@ __global__ __launch_bounds__(256) void k_calib_read(const float* __restrict__ x,
 // host side
 // ---------------------------------------------------------------------------------------
 constexpr int kDirectGridCap = 512;
-constexpr int kNumCU = 256;
+// compute units of the current device, queried once (256 on MI355X; the persistent grids are sized by it)
+inline int num_cus() {
+  static const int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu < 1)
+      cu = 256;
+    return cu;
+  }();
+  return n;
+}
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1724,7 +1783,7 @@ int launch_codelet(const MapGeom& g, float* out, hipStream_t st) {
   using Cfg = CodeletCfg<HP, WP>;
   const long long ngroups = (g.nmaps + Cfg::G - 1) / Cfg::G;
   long long blocks = (ngroups + Cfg::WAVES - 1) / Cfg::WAVES;
-  const long long cap = (long long)kNumCU * 32 / Cfg::WAVES;  // one full residency of waves
+  const long long cap = (long long)num_cus() * 32 / Cfg::WAVES;  // one full residency of waves
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_energy_codelet<HP, WP, PAD, STORE>), dim3((unsigned)blocks),
@@ -1749,7 +1808,7 @@ int launch_codelet_dma(const MapGeom& g, float* out, hipStream_t st) {
         n = 1;
       return n;
     }();
-    const long long cap = (long long)kNumCU * per_cu;
+    const long long cap = (long long)num_cus() * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((k_energy_codelet_dma<N>), dim3((unsigned)blocks), dim3(64 * Cfg::WAVES), 0, st, g, out);
@@ -1922,15 +1981,54 @@ int launch_fused(const TileBatch& tb, hipStream_t st) {
       n = 1;
     return n;
   }();
-  const long long cap = (long long)kNumCU * per_cu;
+  const long long cap = (long long)num_cus() * per_cu;
   const long long grid = tb.total < cap ? tb.total : cap;
   hipLaunchKernelGGL((k_split_fused<M, L>), dim3((unsigned)grid), dim3(64 << L), 0, st, tb);
   return (int)hipGetLastError();
 }
 
+template <class Kernel, class Assemble>
+int run_coeff_chunks(Kernel kernel, Assemble assemble, int N, int threads, const float* x, long long nmaps, float* out,
+                     float* scratch, long long scratch_maps, hipStream_t st) {
+  if (!scratch || scratch_maps < 1) return DCTS_E_WORKSPACE;
+  for (long long m0 = 0; m0 < nmaps; m0 += scratch_maps) {
+    const long long nb = (nmaps - m0) < scratch_maps ? (nmaps - m0) : scratch_maps;
+    TileBatch tb;
+    for (int i = 0; i < kTileItems; ++i) {
+      tb.x[i] = x + m0 * (long long)N * N;
+      tb.out[i] = nullptr;  // the coefficient instantiations write no energies
+      tb.begin[i] = 0;
+    }
+    tb.begin[1] = tb.begin[kTileItems] = nb;
+    tb.map_elems = (long long)N * N;
+    tb.total = nb;
+    tb.count = 1;
+    const long long grid = nb < num_cus() ? nb : num_cus();
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), 0, st, tb, scratch);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    rc = assemble(scratch, nb, out + m0 * (long long)N * N, st);
+    if (rc) return rc;
+  }
+  return DCTS_OK;
+}
+
 }  // namespace
 #if DCTS_PART(3)
 namespace dctsi {
+int dispatch_fused_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps,
+                         hipStream_t st) {
+#define DCTS_CASE(N_, M_, L_)                                                                                        \
+  case N_:                                                                                                           \
+    return run_coeff_chunks(k_split_fused_coeff<M_, L_>, launch_assemble<M_, L_, true>, N_, 64 << L_, x, nmaps, out, \
+                            scratch, scratch_maps, st);
+  switch (N) {
+    DCTS_FUSED_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
 int dispatch_fused(int N, const void* tile_batch, hipStream_t st) {
   const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
 #define DCTS_CASE(N_, M_, L_) \
@@ -1964,7 +2062,7 @@ bool has_fused2(long long N) {
 
 template <int M, int L>
 int launch_fused2(const TileBatch& tb, hipStream_t st) {
-  const long long cap = kNumCU;  // LDS: one workgroup per CU
+  const long long cap = num_cus();  // LDS: one workgroup per CU
   const long long grid = tb.total < cap ? tb.total : cap;
   hipLaunchKernelGGL((k_split_fused2<M, L>), dim3((unsigned)grid), dim3(64 * Fused2Cfg<M, L>::NW), 0, st, tb);
   return (int)hipGetLastError();
@@ -1972,6 +2070,19 @@ int launch_fused2(const TileBatch& tb, hipStream_t st) {
 }  // namespace
 #if DCTS_PART(6)
 namespace dctsi {
+int dispatch_fused2_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps,
+                          hipStream_t st) {
+#define DCTS_CASE(N_, M_, L_)                                                                                      \
+  case N_:                                                                                                         \
+    return run_coeff_chunks(k_split_fused2_coeff<M_, L_>, launch_assemble<M_, L_, true>, N_,                       \
+                            64 * Fused2Cfg<M_, L_>::NW, x, nmaps, out, scratch, scratch_maps, st);
+  switch (N) {
+    DCTS_FUSED2_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
 int dispatch_fused2(int N, const void* tile_batch, hipStream_t st) {
   const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
 #define DCTS_CASE(N_, M_, L_) \
@@ -2011,7 +2122,7 @@ int launch_pipe(const TileBatch& tb, hipStream_t st) {  // one tensor per launch
       n = 1;
     return n;
   }();
-  const long long cap = (long long)kNumCU * per_cu;
+  const long long cap = (long long)num_cus() * per_cu;
   int rc = 0;
   for (int i = 0; i < tb.count && !rc; ++i) {
     const long long nm = tb.begin[i + 1] - tb.begin[i];
@@ -2070,7 +2181,7 @@ template <int HP, int WP, int PAD>
 int launch_codelet_multi(const MultiGeom& mg, hipStream_t st) {
   using Cfg = CodeletCfg<HP, WP>;
   long long blocks = (mg.total_groups + Cfg::WAVES - 1) / Cfg::WAVES;
-  const long long cap = (long long)kNumCU * 32 / Cfg::WAVES;
+  const long long cap = (long long)num_cus() * 32 / Cfg::WAVES;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_energy_codelet_multi<HP, WP, PAD>), dim3((unsigned)blocks), dim3(64 * Cfg::WAVES), 0, st,
@@ -2090,7 +2201,7 @@ int launch_lane(const MultiGeom& mg, hipStream_t st) {
     return n;
   }();
   long long blocks = (mg.total_groups + Cfg::WAVES - 1) / Cfg::WAVES;
-  const long long cap = (long long)kNumCU * per_cu;
+  const long long cap = (long long)num_cus() * per_cu;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_energy_lane_multi<N>), dim3((unsigned)blocks), dim3(64 * Cfg::WAVES), 0, st, mg);
@@ -2173,6 +2284,9 @@ bool has_tile2d(long long N) { return N == 224; }
 
 int tile_family(int HP, int algo) {
   if (algo == DCTS_ALGO_TILE2D) return has_tile2d(HP) ? 4 : 0;
+  // AUTO order: 2-D split (tile2d.hip), pipelined, two-roles, fused. 224: 2-D split 33-42 % of the HBM
+  // peak against 31-37 % pipelined, same box, 996...16384 maps
+  if (algo == DCTS_ALGO_AUTO && has_tile2d(HP)) return 4;
   if (algo == DCTS_ALGO_PIPE) return has_pipe(HP) && has_fused(HP) ? 3 : 0;
   if (algo == DCTS_ALGO_AUTO && has_pipe(HP) && has_fused(HP)) return 3;
   if (has_fused2(HP) && (algo == DCTS_ALGO_FUSED || DCTS_FUSED2_AUTO)) return 2;
@@ -2280,7 +2394,22 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       return dispatch_split((int)HP, g, out, workspace, st);
     }
   } else {
-    if (algo == DCTS_ALGO_SPLIT || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) return DCTS_E_UNSUPPORTED;
+    if (algo == DCTS_ALGO_SPLIT || algo == DCTS_ALGO_PIPE) return DCTS_E_UNSUPPORTED;
+    if (algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_TILE2D) {
+      // coefficients through the large-tile kernels themselves (leaf outputs + k_assemble): what the
+      // parity tests use to check that those kernels compute the DCT and not merely its energy
+      const bool dense = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous && strideC == H * W &&
+                         (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
+      if (!dense) return DCTS_E_UNSUPPORTED;
+      const long long tile_bytes = (long long)HP * WP * 4;
+      const long long ws_maps = workspace ? (long long)(workspace_bytes / (size_t)tile_bytes) : 0;
+      if (ws_maps < 1 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return DCTS_E_WORKSPACE;
+      const float* x0 = x + (long long)c_begin * strideC;
+      float* scratch = reinterpret_cast<float*>(workspace);
+      if (algo == DCTS_ALGO_TILE2D) return dctsi::dispatch_tile2d_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
+      if (has_fused2(HP)) return dctsi::dispatch_fused2_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
+      return dctsi::dispatch_fused_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
+    }
   }
 
   const DirectWs ws = direct_ws(g.nmaps, (int)HP, (int)WP);

@@ -229,4 +229,95 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// ---------------------------------------------------------------------------------------
+// coefficient assembly (debug / parity path: dcts_dct2d_f32_ex with a large-tile family)
+// ---------------------------------------------------------------------------------------
+// The energy kernels stop at the leaf outputs of the 2^L roles and fold the last add/sub layer of
+// every DCT-IV node above the leaves into the reduction ((a+b)^2 + (a-b)^2 = 2a^2 + 2b^2, the sqrt(2)
+// in SplitNode::wt). For coefficient output that layer is applied explicitly: coefficient u of the
+// length-N DCT-II is a signed sum of at most 2^ceil(L/2) leaf outputs (DCT-II nodes interleave their
+// children's outputs; a DCT-IV node's are X[0] = A[0], X[n-1] = -B[0], X[2j] = A[j] + B[n/2-j],
+// X[2j-1] = A[j] - B[n/2-j]; DCT-IV nodes only have DCT-II children, so a path holds at most
+// ceil(L/2) of them). invw undoes the amplitude weight the energy kernels apply to a leaf output.
+template <int M, int L>
+struct AsmTable {
+  static constexpr int N = M << L, MAXT = 1 << ((L + 1) / 2);
+  short idx[N][MAXT] = {};  // role * M + k
+  signed char sgn[N][MAXT] = {};
+  unsigned char n[N] = {};
+  float invw[N] = {};       // 1 / weight of leaf output role * M + k
+  constexpr void walk(int level, int path, bool is4, int len, int i, int sign, int u) {
+    if (level == L) {
+      idx[u][n[u]] = short(path * M + i);
+      sgn[u][n[u]] = (signed char)sign;
+      ++n[u];
+      return;
+    }
+    if (!is4) {
+      walk(level + 1, path * 2 + (i & 1), (i & 1) != 0, len / 2, i >> 1, sign, u);
+    } else {
+      const int H = len / 2;
+      if (i == 0) {
+        walk(level + 1, path * 2, false, H, 0, sign, u);
+      } else if (i == len - 1) {
+        walk(level + 1, path * 2 + 1, false, H, 0, -sign, u);
+      } else if (i % 2 == 0) {
+        walk(level + 1, path * 2, false, H, i / 2, sign, u);
+        walk(level + 1, path * 2 + 1, false, H, H - i / 2, sign, u);
+      } else {
+        const int j = (i + 1) / 2;
+        walk(level + 1, path * 2, false, H, j, sign, u);
+        walk(level + 1, path * 2 + 1, false, H, H - j, -sign, u);
+      }
+    }
+  }
+  template <int R>
+  constexpr void weights() {
+    using Leaf = typename RoleLeaf<N, L, R>::type;
+    for (int k = 0; k < M; ++k) invw[R * M + k] = float(1.0 / Leaf::wt(k == 0));
+  }
+  template <int... R>
+  constexpr void all_weights(std::integer_sequence<int, R...>) {
+    (weights<R>(), ...);
+  }
+  constexpr AsmTable() {
+    for (int u = 0; u < N; ++u) walk(0, 0, false, N, u, 1, u);
+    all_weights(std::make_integer_sequence<int, (1 << L)>{});
+  }
+};
+template <int M, int L>
+__device__ const AsmTable<M, L> kAsmTable{};
+
+// leaf[b][iH][iW] (iH = roleH * M + kH, iW likewise; weighted iff WEIGHTED) -> out[b][u][v], the
+// orthonormal coefficients of torch_dct.dct_2d(norm='ortho') (utils/common.py:267)
+template <int M, int L, bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_assemble(const float* __restrict__ leaf, long long nmaps, float* __restrict__ out) {
+  constexpr int N = M << L;
+  const AsmTable<M, L>& t = kAsmTable<M, L>;
+  const long long total = nmaps * N * N;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long b = e / (N * N);
+    const int uv = (int)(e - b * (N * N)), u = uv / N, v = uv - u * N;
+    const float* lf = leaf + b * (long long)N * N;
+    float acc = 0.f;
+    for (int i = 0; i < t.n[u]; ++i)
+      for (int j = 0; j < t.n[v]; ++j) {
+        const int iH = t.idx[u][i], iW = t.idx[v][j];
+        float val = lf[iH * N + iW];
+        if (WEIGHTED) val *= t.invw[iH] * t.invw[iW];
+        acc += float(t.sgn[u][i] * t.sgn[v][j]) * val;
+      }
+    constexpr float s0 = dcts::ortho_scale<N>(0), s1 = dcts::ortho_scale<N>(1);
+    out[e] = acc * ((u == 0 ? s0 : s1) * (v == 0 ? s0 : s1));
+  }
+}
+template <int M, int L, bool WEIGHTED>
+inline int launch_assemble(const float* leaf, long long nmaps, float* out, hipStream_t st) {
+  const long long total = nmaps * (long long)(M << L) * (M << L);
+  long long blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL((k_assemble<M, L, WEIGHTED>), dim3((unsigned)blocks), dim3(256), 0, st, leaf, nmaps, out);
+  return (int)hipGetLastError();
+}
+
 }  // namespace

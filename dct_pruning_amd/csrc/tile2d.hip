@@ -41,7 +41,8 @@
 
 namespace dctsi {
 int dispatch_tile2d(int N, const void* tile_batch, hipStream_t st);
-int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, hipStream_t st);
+int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps,
+                          hipStream_t st);
 }  // namespace dctsi
 
 namespace {
@@ -100,11 +101,11 @@ constexpr T2Sched kT2Sch{};
 // The item slots (a, b) whose outputs belong to `set`, ordered by column slot b then a: slot i of
 // the set as a * S + b. A slot's register is free for the next map's sample once the set has been
 // written to LDS, so the next map is loaded set by set, eight slots per hook point.
-constexpr int t2_set_slot(int set, int i) {
+constexpr int t2_set_slot(int set, int i, int bmax) {
   int role_of_slot[kT2S] = {};
   for (int r = 0; r < kT2S; ++r) role_of_slot[kT2Plan.slot_of_role[r]] = r;
   int n = 0;
-  for (int b = 0; b < kT2S; ++b)
+  for (int b = 0; b < bmax; ++b)
     for (int a = 0; a < kT2S; ++a)
       if (kT2Sch.set_of[role_of_slot[a] * kT2S + role_of_slot[b]] == set) {
         if (n == i) return a * kT2S + b;
@@ -112,8 +113,16 @@ constexpr int t2_set_slot(int set, int i) {
       }
   return -1;
 }
-// load order of a map's 64 slots: set 0's (free first), then set 1's
-constexpr int t2_load_slot(int i) { return i < kT2S * kT2S / 2 ? t2_set_slot(0, i) : t2_set_slot(1, i - kT2S * kT2S / 2); }
+constexpr int t2_set_count(int set, int bmax) {
+  int n = 0;
+  while (t2_set_slot(set, n, bmax) >= 0) ++n;
+  return n;
+}
+// load order of the slots with b < bmax: set 0's (free first), then set 1's
+constexpr int t2_load_slot(int i, int bmax) {
+  const int n0 = t2_set_count(0, bmax);
+  return i < n0 ? t2_set_slot(0, i, bmax) : t2_set_slot(1, i - n0, bmax);
+}
 
 template <int M>
 struct T2Cfg {
@@ -128,9 +137,22 @@ struct T2Cfg {
   static constexpr int PWAVES = (M + PI - 1) / PI;    // producer waves (14 for M = 28)
   static_assert(PWAVES <= NW, "producers");
   static constexpr int NROT = 3;                      // rotations of the L = 3 network
-#ifndef DCTS_T2_HOOKS
-#define DCTS_T2_HOOKS 10, 11, 11, 10, 11, 11
+#ifndef DCTS_T2_DMACOLS
+#define DCTS_T2_DMACOLS 2
 #endif
+#ifndef DCTS_T2_HOOKS
+#define DCTS_T2_HOOKS 0, 0, 0, 12, 12, 12
+#endif
+  // The last DB column slots of the NEXT map do not land in registers but in LDS (direct-to-LDS
+  // loads into the 56 KB the Z set leaves free: no VGPRs, nothing for the register allocator to
+  // spill), issued while set 0 is transformed; phase A reads them from there.
+  static constexpr int DB = DCTS_T2_DMACOLS;
+  static constexpr int VB = S - DB;                    // column slots loaded into registers
+  static constexpr int NV = S * VB;                    // ... = loads per lane and map
+  static constexpr int RAWW = DB * M;                  // floats per row of the raw image in LDS
+  static constexpr int RAW = N * RAWW;                 // floats
+  static constexpr int RAW_PIECES = (RAW / 4 + 63) / 64;  // 1 KiB direct-to-LDS instructions per map
+  static_assert((RAWW % 4) == 0 && ((VB * M) % 4) == 0, "16-byte pieces");
   // next-map loads at the six hook points of a map (three per pass: before axis A, between the axes,
   // after axis B; first the pass of set 0, then that of set 1); what is left goes out after the passes
   static constexpr int HOOKS[6] = {DCTS_T2_HOOKS};
@@ -139,7 +161,8 @@ struct T2Cfg {
     for (int i = 0; i < h; ++i) n += HOOKS[i];
     return n;
   }
-  static_assert(hook_begin(3) <= S * S / 2 && hook_begin(6) <= S * S, "a slot is loaded after its set has gone to LDS");
+  static_assert(hook_begin(6) <= NV, "loads per map");
+  // (a slot must not be loaded before its set has gone to LDS: checked where the hooks are built)
 };
 
 // rotation constants (c, s, sigma*c, sigma*s), sigma = (-1)^j of the pair index: [rot][p][4]
@@ -165,6 +188,7 @@ __device__ const T2RotTable<M> kT2Rot{};
 struct T2BlockParam {
   int tA, tB;                    // 1: DCT-IV along p' (A) / q' (B)
   int variant;                   // tA * 4 + tB(first block) * 2 + tB(second block) of the pass
+  int block;                     // ra * S + rb
   float wA0, wA1, wB0, wB1;      // squared weights of output 0 / outputs > 0 per axis
 };
 template <int M>
@@ -188,6 +212,7 @@ constexpr T2ParamTable<M> t2_make_params(std::integer_sequence<int, R...>) {
   for (int s = 0; s < 2; ++s)
     for (int li = 0; li < kT2S * kT2S / 2; ++li) {
       const int ra = sch.blk[s][li] / kT2S, rb = sch.blk[s][li] % kT2S;
+      t.v[s][li].block = sch.blk[s][li];
       t.v[s][li].tA = plan.is4_of_role[ra];
       t.v[s][li].tB = plan.is4_of_role[rb];
       t.v[s][li].wA0 = w0[ra];
@@ -350,8 +375,12 @@ __device__ __forceinline__ float t2_axis_b(const T2Pass<M>& ps, int set, float* 
     lds_cptr src = ps.blk + (ps.act ? ps.j : 0) * RS;
     dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { z[decltype(i)::value] = src[decltype(i)::value]; });
     float t0 = 0.f, t1 = 0.f;
-    // debug / parity path: leaf outputs, unweighted, as [set * 32 + li][k1][k2]
-    float* o = STORE ? leaf_out + ((long long)(set * (kT2S * kT2S / 2) + ps.li) * M + ps.j) * M : nullptr;
+    // debug / parity path: leaf outputs, unweighted, as [ra * M + k1][rb * M + k2] (k_assemble's layout)
+    float* o = nullptr;
+    if constexpr (STORE) {
+      const int blk_id = __builtin_bit_cast(int, ps.pp[7]);
+      o = leaf_out + ((long long)((blk_id / kT2S) * M + ps.j) * (M * kT2S) + (blk_id % kT2S) * M);
+    }
     auto sq = [&](auto k, float val) DCTS_LAMBDA_INLINE {
       if constexpr (decltype(k)::value == 0)
         t0 = val * val;
@@ -432,6 +461,21 @@ __device__ __forceinline__ float t2_axis_b_chain(int vid, const T2Pass<M>& ps, f
   }
 }
 
+// The four waves of a SIMD (wave, wave + 4, ... of the workgroup) are arbitrated oldest first: in an
+// issue-bound phase the youngest ran at half the speed of the oldest (stamps: 8.0 k vs 4.5 k cycles
+// for the same pass) and everybody then waits for it at the barrier. Rotating a static priority
+// through the four of them at every hook point evens their progress out.
+__device__ __forceinline__ void t2_rotate_prio(int wave, int step) {
+#ifdef DCTS_T2_PRIO  // measured neutral (the phases are issue-bound: evening the waves out moves time from the barriers into the phases), off
+  switch (((wave >> 2) + step) & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+#endif
+}
+
 // One pass with the caller's hook at three points: before axis A, between the axes, after axis B.
 // The caller trickles the next map's loads out there: a burst of loads blocks the issuing wave until
 // the CU's miss queue has room (stamps: 10 k cycles per map for 32 loads per wave in one go, i.e. the
@@ -439,10 +483,12 @@ __device__ __forceinline__ float t2_axis_b_chain(int vid, const T2Pass<M>& ps, f
 template <int M, int SET, bool STORE, class Hook>
 __device__ __forceinline__ float t2_consume(int vid, lds_ptr zbuf, lds_cptr params, int wave, int lane, float* leaf_out, Hook hook) {
   const T2Pass<M> ps(zbuf, params, SET, wave, lane);
+  t2_rotate_prio(wave, 2 * SET);
   hook(std::integral_constant<int, 0>{});
   __builtin_amdgcn_sched_barrier(0);
   t2_axis_a_chain<M, SET>(vid, ps);
   __builtin_amdgcn_sched_barrier(0);
+  t2_rotate_prio(wave, 2 * SET + 1);
   hook(std::integral_constant<int, 1>{});
   __builtin_amdgcn_sched_barrier(0);
   // the wave's own LDS traffic is in order; only the compiler must not reorder
@@ -486,7 +532,7 @@ __device__ __forceinline__ void t2_load_seq(const float* __restrict__ in_b, int 
   const int pe = p, po = M - 1 - p, qe = q, qo = M - 1 - q;
   const int o_ee = (pe * N + qe) * 4, o_eo = (pe * N + qo) * 4, o_oe = (po * N + qe) * 4, o_oo = (po * N + qo) * 4;
   dcts::static_for<(I1 > I0 ? I1 - I0 : 0)>([&](auto ii) DCTS_LAMBDA_INLINE {
-    constexpr int sl = t2_load_slot(I0 + decltype(ii)::value);
+    constexpr int sl = t2_load_slot(I0 + decltype(ii)::value, T2Cfg<M>::VB);
     static_assert(sl >= 0, "slot");
     constexpr int a = sl / kT2S, b = sl % kT2S;
     const int voff = (a % 2 == 0) ? ((b % 2 == 0) ? o_ee : o_eo) : ((b % 2 == 0) ? o_oe : o_oo);
@@ -494,9 +540,28 @@ __device__ __forceinline__ void t2_load_seq(const float* __restrict__ in_b, int 
   });
 }
 
+// piece `i` (64 lanes x 16 B) of the raw image: rows 0..N-1, columns [VB*M, N) of the map, dense
+// [row][RAWW] in LDS. Raw instruction (ordering is the kernel's own s_waitcnt vmcnt(0) + barrier;
+// see FusedStage::piece_raw in dct_kernels.hip for why not the builtin).
+template <int M>
+__device__ __forceinline__ void t2_dma_piece(const float* __restrict__ in_b, lds_ptr raw, int i, int lane) {
+  using Cfg = T2Cfg<M>;
+  constexpr int QPR = Cfg::RAWW / 4;  // quads per row
+  const int f = i * 64 + lane;
+  if (f < Cfg::RAW / 4) {
+    const int row = f / QPR, cq = f - row * QPR;
+    const unsigned off = (unsigned)(row * Cfg::N + Cfg::VB * M + 4 * cq) * 4u;  // bytes
+    const unsigned dst = (unsigned)(unsigned long long)(raw + i * 256);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 :
+                 : "s"(dst), "v"(off), "s"(in_b)
+                 : "memory", "m0");
+  }
+}
+
 template <int M, class Src, bool STORE>
-__device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot, lds_ptr params, lds_ptr partials,
-                                        float* leaf_out) {
+__device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw, lds_ptr rot, lds_ptr params,
+                                        lds_ptr partials, float* leaf_out) {
   using Cfg = T2Cfg<M>;
   constexpr int S = kT2S, RS = Cfg::RS, BS = Cfg::BS, NROT = Cfg::NROT;
   const int lane_in = threadIdx.x & 63;
@@ -516,6 +581,7 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot
     params[i * 8 + 4] = bp.wB0;
     params[i * 8 + 5] = bp.wB1;
     params[i * 8 + 6] = __builtin_bit_cast(float, bp.variant);
+    params[i * 8 + 7] = __builtin_bit_cast(float, bp.block);
   }
   const bool producer = wave < Cfg::PWAVES;
   const long long nmaps = tb.total;
@@ -541,7 +607,12 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot
     int p, q;
     bool ok;
     item_pq(p, q, ok);
-    t2_load<M, 0, S>(tile_in(tb, m), p, q, v);  // grid <= nmaps: every workgroup owns a map
+    const float* first = tile_in(tb, m);  // grid <= nmaps: every workgroup owns a map
+    t2_load<M, 0, Cfg::VB>(first, p, q, v);
+    if constexpr (Cfg::DB > 0) {
+      for (int i = wave; i < Cfg::RAW_PIECES; i += kT2Waves) t2_dma_piece<M>(first, raw, i, lane_in);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed (the barrier below publishes them)
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   auto finish = [&]() DCTS_LAMBDA_INLINE {
@@ -551,7 +622,7 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot
 #pragma unroll
         for (int i = 0; i < kT2Waves; ++i) t += partials[pending_slot * kT2Waves + i];
         constexpr float sc = float(4.0 / (double(Cfg::N) * double(Cfg::N)));
-        *tile_out(tb, pending_m) = t * sc;
+        if constexpr (!STORE) *tile_out(tb, pending_m) = t * sc;  // the coefficient path has no energy output
       }
       pending_m = -1;
     }
@@ -573,7 +644,17 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot
       dcts::static_for<S>([&](auto ib) DCTS_LAMBDA_INLINE {
         constexpr int b = decltype(ib)::value;
         float y[S];
-        dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE { y[decltype(ia)::value] = v[decltype(ia)::value][b]; });
+        if constexpr (b < Cfg::VB) {
+          dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE { y[decltype(ia)::value] = v[decltype(ia)::value][b]; });
+        } else {
+          // this column slot of the map landed in LDS (raw image [row][RAWW])
+          const int qq = (b % 2 == 0) ? q : M - 1 - q;
+          dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE {
+            constexpr int a = decltype(ia)::value;
+            const int row = a * M + ((a % 2 == 0) ? p : M - 1 - p);
+            y[a] = raw[row * Cfg::RAWW + (b - Cfg::VB) * M + qq];
+          });
+        }
         t2_network<M>(y, rp);
         dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE { v[decltype(ia)::value][b] = y[decltype(ia)::value]; });
         // one network at a time: interleaved for ILP the eight of them run the registers out, and what
@@ -635,10 +716,17 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot
     // workgroup; so do 64 landing + 44.
     const bool more = m + gridDim.x < nmaps;
     const float* nsrc = tile_in(tb, more ? m + gridDim.x : m);  // last map: reload it (unused), see above
+    static_assert(Cfg::hook_begin(3) <= t2_set_count(0, Cfg::VB), "a slot is loaded after its set has gone to LDS");
     auto trickle = [&](auto set) DCTS_LAMBDA_INLINE {
       return [&](auto k) DCTS_LAMBDA_INLINE {
         constexpr int h = 3 * decltype(set)::value + decltype(k)::value;
         constexpr int i0 = Cfg::hook_begin(h), n = Cfg::HOOKS[h];
+        if constexpr (decltype(set)::value == 0 && Cfg::DB > 0) {
+          // the raw image is free since barrier #1 (phase A has read it): the next map's pieces, one
+          // per wave and hook point (49 for 224x224; the 16 waves issue 16 at a time)
+          constexpr int kk = decltype(k)::value;
+          for (int i = wave + kT2Waves * kk; i < Cfg::RAW_PIECES; i += 3 * kT2Waves) t2_dma_piece<M>(nsrc, raw, i, launder(lane_in));
+        }
         if constexpr (n > 0) {
           int p, q;
           bool ok;
@@ -654,18 +742,19 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr rot
     T2_STAMP(5);
     if (producer) write_set(std::integral_constant<int, 1>{});
     T2_STAMP(6);
+    if constexpr (Cfg::DB > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of the next map's raw image have landed
     lds_barrier();  // #3
     T2_STAMP(7);
     T2_STAMP(8);
     e += t2_consume<M, 1, STORE>(vid1, zbuf, params, wave, launder(lane_in), lo, trickle(std::integral_constant<int, 1>{}));
     asm volatile("" : "+v"(e));
     T2_STAMP(9);
-    if constexpr (Cfg::hook_begin(6) < S * S) {
+    if constexpr (Cfg::hook_begin(6) < Cfg::NV) {
       asm volatile("" ::: "memory");
       int p, q;
       bool ok;
       item_pq(p, q, ok);
-      t2_load_seq<M, Cfg::hook_begin(6), S * S>(nsrc, p, q, v);
+      t2_load_seq<M, Cfg::hook_begin(6), Cfg::NV>(nsrc, p, q, v);
       __builtin_amdgcn_sched_barrier(0);
     }
     e = wave_sum_dpp(e);
@@ -687,10 +776,11 @@ template <int M, bool STORE>
 __global__ __launch_bounds__(64 * kT2Waves) void k_tile2d(TileBatch tb, float* leaf_out) {
   using Cfg = T2Cfg<M>;
   __shared__ __attribute__((aligned(16))) float zbuf[Cfg::ZSET];
+  __shared__ __attribute__((aligned(16))) float raw[Cfg::RAW > 0 ? Cfg::RAW_PIECES * 256 : 4];
   __shared__ __attribute__((aligned(16))) float rot[Cfg::NROT * M * 4];
   __shared__ __attribute__((aligned(16))) float params[2 * (kT2S * kT2S / 2) * 8];
   __shared__ float partials[2 * kT2Waves];
-  t2_body<M, TileBatch, STORE>(tb, (lds_ptr)zbuf, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
+  t2_body<M, TileBatch, STORE>(tb, (lds_ptr)zbuf, (lds_ptr)raw, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
 }
 
 #define DCTS_TILE2D_TABLE(X) X(224, 28)
@@ -749,7 +839,33 @@ int dispatch_tile2d(int N, const void* tile_batch, hipStream_t st) {
   }
 #undef DCTS_CASE
 }
-int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, hipStream_t st) {
-  return DCTS_E_UNSUPPORTED;
+// coefficient output (debug / parity): the same kernel with the leaf outputs stored, then the DCT-IV
+// add/sub layers above the leaves, the orthonormal scale and the role -> frequency index map
+// (k_assemble). `scratch` holds scratch_maps tiles; maps go through it in chunks.
+int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps,
+                          hipStream_t st) {
+  if (N != 224) return DCTS_E_UNSUPPORTED;
+  if (!scratch || scratch_maps < 1) return DCTS_E_WORKSPACE;
+  constexpr int M = 28;
+  for (long long m0 = 0; m0 < nmaps; m0 += scratch_maps) {
+    const long long nb = (nmaps - m0) < scratch_maps ? (nmaps - m0) : scratch_maps;
+    TileBatch tb;
+    for (int i = 0; i < kTileItems; ++i) {
+      tb.x[i] = x + m0 * (long long)N * N;
+      tb.out[i] = nullptr;  // the STORE instantiation writes no energies
+      tb.begin[i] = 0;
+    }
+    tb.begin[1] = tb.begin[kTileItems] = nb;
+    tb.map_elems = (long long)N * N;
+    tb.total = nb;
+    tb.count = 1;
+    const long long grid = nb < 256 ? nb : 256;
+    hipLaunchKernelGGL((k_tile2d<M, true>), dim3((unsigned)grid), dim3(64 * kT2Waves), 0, st, tb, scratch);
+    int rc = (int)hipGetLastError();
+    if (rc) return rc;
+    rc = launch_assemble<M, kT2L, false>(scratch, nb, out + m0 * (long long)N * N, st);
+    if (rc) return rc;
+  }
+  return DCTS_OK;
 }
 }  // namespace dctsi

@@ -38,3 +38,13 @@ HARNESS_CASES = {
     "resnet_50": (1, 1, 64, False),
     "u2netp": (1, 1, 72, True),
 }
+
+
+def synth(n, c, h, w, seed, dead=True):
+    """SURVEY.md §8(d) synthetic maps: relu(randn) * per-channel scale, every c % 8 == 5 dead."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.relu(torch.randn(n, c, h, w, generator=g))
+    s = torch.exp(0.5 * torch.randn(c, generator=g))
+    if dead:
+        s[torch.arange(c) % 8 == 5] = 0
+    return x * s[None, :, None, None]
