@@ -1658,8 +1658,8 @@ __global__ __launch_bounds__(kDirectThreads) void k_energy_direct(
   }
 }
 
-// Batch sum over n of E[n][j] for a 32-channel strip per block: 8 n-slices run in parallel
-// (slice s takes n = s, s+8, ...), partials are combined in slice order -> a fixed,
+// Batch sum over n of E[n][j] for a 32-channel strip per block: kSumSl = 16 n-slices run in parallel
+// (slice s takes n = s, s+16, ...), partials are combined in slice order -> a fixed,
 // launch-independent summation order (bit-reproducible, no atomics).
 constexpr int kSumCh = 32, kSumSl = 16;
 __device__ __forceinline__ float strip_batch_sum(const float* __restrict__ e, long long N,
@@ -2367,10 +2367,12 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     return dispatch_codelet<STORE>((int)HP, (int)WP, pad, g, out, st);
   }
   if constexpr (!STORE) {
-    const bool split_ok = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous &&
-                          strideC == H * W;
-    if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
+    // every split kernel stages with 16-byte direct-to-LDS loads: a base that is only 4-byte aligned
+    // takes the direct kernel
     const bool aligned16 = (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
+    const bool split_ok = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous &&
+                          strideC == H * W && aligned16;
+    if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
     if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) {
       const int fam = (split_ok && aligned16) ? tile_family((int)HP, algo) : 0;
       if (fam) {
@@ -2391,6 +2393,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     if (split_ok && algo != DCTS_ALGO_DIRECT) {
       const SplitWs sws = split_ws(g.nmaps, (int)HP);
       if (!workspace || workspace_bytes < sws.total) return DCTS_E_WORKSPACE;
+      if (reinterpret_cast<uintptr_t>(workspace) & 15) return DCTS_E_ALIGN;  // pass 2 stages the intermediate the same way
       return dispatch_split((int)HP, g, out, workspace, st);
     }
   } else {
@@ -2442,7 +2445,7 @@ const char* dcts_strerror(int code) {
     case DCTS_E_STRIDE: return "rows must be dense: strideW == 1 and strideH >= W";
     case DCTS_E_WORKSPACE: return "workspace missing or smaller than dcts_workspace_bytes()";
     case DCTS_E_UNSUPPORTED: return "no kernel of the requested family for this shape";
-    case DCTS_E_ALIGN: return "pointer not 4-byte aligned";
+    case DCTS_E_ALIGN: return "pointer not 4-byte aligned (tensors) / 16-byte aligned (workspace)";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);

@@ -95,8 +95,10 @@ size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W);
  *                   (np.pad(t,(1,0)) pads every axis; the test is on H only).
  *   out_nc       [N, c_count] fp32, row-major:
  *                out_nc[n*c_count + j] = sum_{u,v} DCT2_ortho(x[n, c_begin+j])[u,v]^2
- *   workspace    >= dcts_workspace_bytes(N, c_count, H, W) bytes of device memory, or NULL
- *                when that is 0.
+ *   workspace    >= dcts_workspace_bytes(N, c_count, H, W) bytes of device memory, 16-byte aligned,
+ *                or NULL when that is 0. (The size of the two-launch split path's intermediate
+ *                buffer, and with it dcts_workspace_bytes for edges 72..320, follows the environment
+ *                variable DCTS_SPLIT_CHUNK_MB, read once per process; default 256.)
  */
 int dcts_energy_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
                     int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
@@ -119,7 +121,11 @@ int dcts_has_codelet(int64_t H, int64_t W);
  * commented-out variants hint at, utils/common.py:268-269). Same addressing as above;
  *   out_coeff    [N, c_count, H', W'] fp32 dense, H' = H + (pad && H odd), W' likewise;
  *                out_coeff[n,j] = dct_2d(x[n, c_begin+j], norm='ortho').
- *   workspace    as for dcts_energy_f32 (same size query).
+ *   workspace    as for dcts_energy_f32 (same size query). With DCTS_ALGO_FUSED / DCTS_ALGO_TILE2D
+ *                (dcts_dct2d_f32_ex) the large-tile energy kernels themselves produce the coefficients
+ *                (leaf outputs into the workspace, then the DCT-IV add/sub layers the energy path folds
+ *                into its reduction): the workspace must be 16-byte aligned and hold at least one
+ *                H' x W' fp32 tile; more tiles mean fewer launches.
  */
 int dcts_dct2d_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
                    int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
@@ -135,8 +141,9 @@ int dcts_dct2d_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int
 
 /*
  * Fused batch reduction for benchmarking and for the single-sweep harness:
- *   out_c[j] = sum_n energy[n, j]   (fp32, fixed summation order n = 0..N-1, so the result
- *   is bit-identical to torch's  c.view(a,-1).sum(0)  only up to summation order; the
+ *   out_c[j] = sum_n energy[n, j]   (fp32; summation order: 16 interleaved slices, slice s adds
+ *   n = s, s+16, s+32, ... in ascending order, then the 16 partial sums are added in slice order.
+ *   Fixed, launch-independent and bit-reproducible, but not torch's c.view(a,-1).sum(0) order: the
  *   reference-exact path is dcts_energy_f32 + host-side sum(0), utils/common.py:271-274).
  */
 int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float* out_c,
@@ -166,7 +173,7 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
  * feature_result is [C_count] fp32 in/out on the device (zeros before the first batch, like
  * the reference's torch.tensor(0.) broadcast); the caller keeps `total` on the host and
  * adds N after each call. Same three fp32 roundings as the reference (no FMA contraction);
- * the batch sum runs n = 0..N-1 in order.
+ * the batch sum is the 16-slice fixed-order sum of dcts_batch_sum_f32.
  */
 int dcts_running_mean_update_f32(const float* energy_nc, int64_t N, int64_t C_count,
                                  float* feature_result, float total_before, void* stream);

@@ -1,0 +1,47 @@
+"""bench.py is self-launching: `python bench.py --gpus N` starts its own torch.distributed.run child
+(the command the driver uses for the scaling runs). Rehearsed here with two ranks on the one GPU
+(DCTS_BENCH_REHEARSE=1: every rank on cuda:0, the collective over gloo); a real multi-GPU box runs
+the same code with one GPU per rank over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, rehearse=False):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    if rehearse:
+        env["DCTS_BENCH_REHEARSE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks():
+    common = ["--batch", "16", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-headline"]
+    one = run_bench("--gpus", "1", *common)
+    two = run_bench("--gpus", "2", *common, rehearse=True)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "strong" and "all_gather_ms" in two and "all_gather_ms" not in one
+    assert two["config"]["sharding"].startswith("layer-sharded")
+    for r in (one, two):
+        assert r["unit"] == "Mmaps/s" and r["roofline"]["bound"] == "hbm" and r["parity_check_rel_err"] <= 1e-4
+        assert r["dead_channels_not_plus_zero"] == 0
+    # two ranks share ONE GPU here, so there is no speed-up to expect; the rehearsal must stay in the
+    # same ballpark as the single-rank run (it pays the gloo round trip through host memory)
+    assert two["value"] >= 0.2 * one["value"]
+
+
+def test_bench_u2netp_at_320():
+    """BASELINE.json config 5 names a 320x320 input (the reference crops to 288)."""
+    r = run_bench("--net", "u2netp", "--input-size", "320", "--batch", "2", "--steps", "3", "--warmup", "1",
+                  "--no-cpu-baseline", "--no-headline")
+    assert "320x320" in r["config"]["workload"] and r["roofline"]["kernel"].startswith("k_split_fused2")

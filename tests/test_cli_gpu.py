@@ -1,7 +1,7 @@
 """End to end on the GPU: importance_generation.py (the reference's CLI surface) -> score files ->
 prune masks, for BASELINE.json config 2 (VGG-16-bn / CIFAR shapes, limit 5) at a reduced batch and
-a ResNet-50 / 224x224 run at batch 2. Masks are compared with the masks of scores computed by
-the CPU oracle on the very same activations."""
+a ResNet-50 / 224x224 run at batch 2: file list, format and scores (1e-4 against the CPU oracle on a
+second forward pass). Strict mask equality on identical activations: tests/test_mask_parity_gpu.py."""
 import os
 import subprocess
 import sys
@@ -11,12 +11,19 @@ import numpy as np
 import pytest
 import torch
 
-from dct_pruning_amd import harness, masks, nets, schedules
+from dct_pruning_amd import harness, nets, schedules
 from dct_pruning_amd.data import load_data
 from oracle import dct_oracle as orc
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
 def run_cli(tmp_path, *argv):
@@ -51,7 +58,7 @@ def oracle_scores(name, args, points):
 
 @pytest.mark.parametrize("name,bs,limit,extra", [("vgg_16_bn", 32, 5, []), ("resnet_50", 2, 2, []),
                                                   ("vgg_16_bn", 32, 5, ["--single_sweep", "--device_accumulate"])])
-def test_cli_to_masks(tmp_path, name, bs, limit, extra):
+def test_cli_scores(tmp_path, name, bs, limit, extra):
     dataset = "imagenet" if name == "resnet_50" else "cifar10"
     out = run_cli(tmp_path, "--net", name, "--dataset", dataset, "--synthetic", "--pretrain_dir", "",
                   "--batch_size", str(bs), "--limit", str(limit), *extra)
@@ -68,14 +75,8 @@ def test_cli_to_masks(tmp_path, name, bs, limit, extra):
         assert got.dtype == np.float32 and got.shape == r.shape
         # the forward pass re-runs here (MIOpen is not bit-reproducible run to run): 1e-4, not bitwise
         np.testing.assert_allclose(got, r, rtol=1e-4, atol=1e-6 * float(r.max()))
-        for rate in (0.3, 0.5, 0.95):
-            k = int(r.size * (1 - rate))
-            a, b = masks.select_index(got, r.size, k), masks.select_index(r, r.size, k)
-            # identical unless a near-tie (|delta| < 1e-4 relative) straddles the cut
-            if not np.array_equal(a, b):
-                diff = np.setxor1d(a, b)
-                cut = np.sort(r)[r.size - k]
-                assert np.all(np.abs(r[diff] - cut) <= 2e-4 * abs(cut)), stem
+        # masks are compared strictly - no near-tie allowance - where the activations are identical on both
+        # sides: tests/test_mask_parity_gpu.py (here the oracle's forward pass is a second MIOpen run)
 
 
 def test_two_rank_cli_equals_single_rank(tmp_path):
@@ -88,7 +89,7 @@ def test_two_rank_cli_equals_single_rank(tmp_path):
     run_cli(tmp_path / "one", *common)
     env = dict(os.environ, PYTHONPATH=ROOT, DCTS_REHEARSE="1")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29733",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                         os.path.join(ROOT, "importance_generation.py"), *common],
                        cwd=tmp_path / "two", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=600)
