@@ -37,7 +37,9 @@ CFG_ID = 4
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="default 20; 200 for workloads whose step is under 1 GB (the CIFAR nets: a step is ~50 us, "
+                         "20 of them would be timed against the fixed cost of the final barrier)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="default 256 (u2netp: 12, README.md:222 of the reference)")
     ap.add_argument("--net", default="resnet_50")
@@ -48,6 +50,9 @@ def parse():
     ap.add_argument("--per-tensor", action="store_true",
                     help="one energy launch per hooked tensor (default: one dcts_energy_multi_f32 launch per tile shape)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--pmc-calib", action="store_true",
+                    help="(tools/profile_bench_pmc.sh) run the known-size calibration read first, so a PMC pass of "
+                         "this process can correct FETCH_SIZE")
     return ap.parse_args()
 
 
@@ -94,8 +99,13 @@ class BoundUnit:
 
 
 def cpu_baseline(points, seconds):
-    """The oracle's restatement of the reference loop (utils/common.py:265-277) on one sample's
-    worth of the same hooked tensors, single thread (the per-map loop is serial Python)."""
+    """The reference CPU path on this box's host cores, two legs:
+    * value (kind "port"): the oracle's restatement of the reference loop (utils/common.py:265-277: one
+      dct_2d + sum + .item() per map in a Python list comprehension) on whole samples of the same hooked
+      tensors. One thread: the loop is serial Python around ~25 tiny torch ops per map, more threads do not
+      make it faster (torch's intra-op pool has nothing to chew on at 56x56) - that IS the reference's CPU path;
+    * batched: the best this host does with the same arithmetic when the Python loop is removed: one
+      batched FFT-DCT over all maps of a tensor, every core torch can use, >= 64 samples per tensor, 3 reps."""
     from oracle import dct_oracle as orc
     from dct_pruning_amd import schedules
 
@@ -122,21 +132,40 @@ def cpu_baseline(points, seconds):
         if time.perf_counter() - t0 >= seconds or reps >= 8:
             break
     dt = time.perf_counter() - t0
-    # best-effort CPU: one batched FFT-DCT over all maps of a tensor, all cores
-    nthr = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(nthr)
-    t1 = time.perf_counter()
-    bmaps = 0
-    for x, kind in tensors:
-        orc.energy_nc_batched(x.expand(8, -1, -1, -1).contiguous(), pad_front_if_odd=(kind != "full"))
-        bmaps += 8 * x.shape[1]
-    dtb = time.perf_counter() - t1
+    # the vectorised leg
+    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))  # what this process may actually use
+    except (AttributeError, OSError):
+        pass
+    # a one-GPU box of this pool shares a 256-CPU host: its share is 16 CPUs per GPU; torch's intra-op pool
+    # on more threads than that share only contends (an unbounded pool made this leg take minutes)
+    ncpu = max(1, min(ncpu, int(os.environ.get("DCTS_BENCH_CPU_THREADS", "32"))))
+    torch.set_num_threads(ncpu)
+    nsamp = 64
+    per_sample = sum(x.shape[1] * x.shape[2] * x.shape[3] * 4 for x, _ in tensors)
+    while nsamp > 8 and nsamp * per_sample > 6e9:  # bound the host memory of a pass (U2-Net-p: 165 MB per sample)
+        nsamp //= 2
+    best, bmaps, passes, tb0 = None, 0, 0, time.perf_counter()
+    for _ in range(3):
+        t1 = time.perf_counter()
+        bmaps = 0
+        for x, kind in tensors:
+            orc.energy_nc_batched(x.expand(nsamp, -1, -1, -1).contiguous(), pad_front_if_odd=(kind != "full"))
+            bmaps += nsamp * x.shape[1]
+        dtb = time.perf_counter() - t1
+        best = dtb if best is None else min(best, dtb)
+        passes += 1
+        if time.perf_counter() - tb0 > 20.0:  # keep the default bench run within minutes
+            break
     return {
         "value": maps / dt / 1e6, "unit": "Mmaps/s", "cores": 1, "kind": "port",
-        "sample": "%d x (1 sample of the %d hooked tensors = %d maps), per-map loop of "
-                  "oracle.get_feature_hook, torch CPU 1 thread, %.1f s" % (reps, len(tensors), maps // reps, dt),
-        "batched": {"value": bmaps / dtb / 1e6, "unit": "Mmaps/s", "cores": nthr,
-                              "sample": "8 samples per tensor, one batched FFT-DCT per tensor"},
+        "sample": "%d x (1 sample of the %d hooked tensors = %d maps), per-map Python loop of oracle.get_feature_hook "
+                  "(restates utils/common.py:265-277), torch CPU, 1 thread because the loop is serial Python, %.1f s"
+                  % (reps, len(tensors), maps // reps, dt),
+        "batched": {"value": bmaps / best / 1e6, "unit": "Mmaps/s", "cores": ncpu, "torch_threads": torch.get_num_threads(),
+                    "sample": "%d samples per tensor (%d maps per pass), one batched FFT-DCT per tensor "
+                              "(oracle.energy_nc_batched), best of %d passes, %.1f s per pass" % (nsamp, bmaps, passes, best)},
         "host_cpus": os.cpu_count(),
     }
 
@@ -266,6 +295,8 @@ def main():
         p = points[u.layer]
         x = synth(N, u.c_hi - u.c_lo, p.H, p.W, 20260104 + 1000 * CFG_ID + 64 * u.layer + (u.c_lo % 61), dev)
         bound.append((i, BoundUnit(lib, x, scored[u.layer][2], stream_ptr, ws_fn(N, u.c_hi - u.c_lo, p.H, p.W))))
+    if args.steps is None:
+        args.steps = 20 if total_cost >= 1e9 else 200
     maps_per_step = N * sum(chans)
     per_edge = {}
     for p, ch in zip(points, chans):
@@ -282,10 +313,21 @@ def main():
     # launch order inside a step: all energy kernels grouped by tile edge (largest first), then ONE
     # fused running-mean launch for every hook point (dcts_running_mean_update_multi_f32)
     bound.sort(key=lambda ib: (-ib[1].h, ib[0]))
-    descs = (_lib.UpdateDesc * len(bound))()
-    for k, (_, b) in enumerate(bound):
-        descs[k].energy_nc, descs[k].feature_result = b.energy.data_ptr(), b.fr.data_ptr()
-        descs[k].N, descs[k].C_count = b.n, b.fr.numel()
+    # one descriptor array per step, built before the clock starts (total_before = samples seen so far): the
+    # host side of a step is then two or more ctypes calls and nothing else - for the CIFAR nets a step is
+    # ~40 us of GPU work, and a Python loop over the hook points per step made the bench host-bound
+    def make_descs(total_before):
+        d = (_lib.UpdateDesc * len(bound))()
+        for k, (_, b) in enumerate(bound):
+            d[k].energy_nc, d[k].feature_result = b.energy.data_ptr(), b.fr.data_ptr()
+            d[k].N, d[k].C_count = b.n, b.fr.numel()
+            d[k].total_before = float(total_before)
+        return d
+
+    descs_by_total = {}
+    for s_ in range(max(args.steps, args.warmup)):
+        descs_by_total[s_ * N] = make_descs(s_ * N)
+    state = {"total": 0}
 
     # multi-launch plan: all units of one tile shape go into one dcts_energy_multi_f32 call
     by_shape = {}
@@ -302,37 +344,69 @@ def main():
         ws = ws_fn(max(b.x.shape[0] for b in bs), max(b.x.shape[1] for b in bs), h, h)
         multi.append((h, arr, len(bs), ws))
 
+    # CIFAR-sized nets: every hooked tensor (tile edges 2..32, whatever the shape) in ONE launch per 48 tensors
+    # (dcts_energy_mixed_f32) instead of one per tile shape
+    mixed = None
+    if not args.per_tensor and bound and all(b.h in (2, 4, 8, 16, 32) and b.x.shape[2] == b.x.shape[3] for _, b in bound):
+        marr = (_lib.ShapedItem * len(bound))()
+        for i, (_, b) in enumerate(bound):
+            t = marr[i].t
+            t.x, t.out_nc = b.x.data_ptr(), b.energy.data_ptr()
+            t.N, t.C_total = b.x.shape[0], b.x.shape[1]
+            t.strideN, t.strideC = b.x.stride(0), b.x.stride(1)
+            t.c_begin, t.c_count = 0, b.x.shape[1]
+            marr[i].H, marr[i].W, marr[i].pad_front_if_odd = b.h, b.h, 0
+        mixed = (marr, len(bound))
+        dom = [b for _, b in bound]  # one kernel covers every tensor: it is the dominant one
+
+    # timing events are created before the clock starts (creating one costs more host time than recording it)
+    ev_pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps * (len(bound) + 2))]
+
+    def new_event():
+        return ev_pool.pop()
+
     def step(events=None):
-        if args.per_tensor:
+        if mixed is not None:
+            if events is not None:
+                ev = new_event()
+                ev.record()
+                events.append(ev)
+            rc = lib.dcts_energy_mixed_f32(mixed[0], mixed[1], None, 0, stream_ptr)
+            if rc:
+                raise RuntimeError("dcts_energy_mixed_f32 -> %d" % rc)
+            if events is not None:
+                ev = new_event()
+                ev.record()
+                events.append(ev)
+        elif args.per_tensor:
             in_dom = False
             for _, b in bound:
                 if events is not None and (b.h == dom_edge) != in_dom:
-                    ev = torch.cuda.Event(enable_timing=True)
+                    ev = new_event()
                     ev.record()
                     events.append(ev)
                     in_dom = not in_dom
                 b.launch_energy()
             if events is not None and in_dom:
-                ev = torch.cuda.Event(enable_timing=True)
+                ev = new_event()
                 ev.record()
                 events.append(ev)
         else:
             for h, arr, n, ws in multi:
                 timed = events is not None and h == dom_edge
                 if timed:
-                    ev = torch.cuda.Event(enable_timing=True)
+                    ev = new_event()
                     ev.record()
                     events.append(ev)
                 rc = lib.dcts_energy_multi_f32(arr, n, h, h, 0, ws.data_ptr(), ws.numel(), stream_ptr)
                 if rc:
                     raise RuntimeError("dcts_energy_multi_f32 -> %d" % rc)
                 if timed:
-                    ev = torch.cuda.Event(enable_timing=True)
+                    ev = new_event()
                     ev.record()
                     events.append(ev)
-        for k, (_, b) in enumerate(bound):
-            descs[k].total_before = b.total
-            b.total += b.n
+        descs = descs_by_total[state["total"]]
+        state["total"] += N
         rc = lib.dcts_running_mean_update_multi_f32(descs, len(bound), stream_ptr)
         if rc:
             raise RuntimeError("dcts_running_mean_update_multi_f32 -> %d" % rc)
@@ -351,19 +425,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.pmc_calib:
+        cal = torch.ones(1 << 28, device=dev)
+        sink = torch.zeros(4, device=dev)
+        for _ in range(3):
+            _lib.check(lib.dcts_debug_stream_read_f32(cal.data_ptr(), cal.numel(), sink.data_ptr(), stream_ptr))
+        torch.cuda.synchronize(dev)
+        del cal
     for _ in range(args.warmup):
         step()
     if world > 1:
         gather()
     for _, b in bound:
         b.fr.zero_()
-        b.total = 0.0
+    state["total"] = 0
 
     events = []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(events)
+    # the dominant kernel is timed with HIP events inside the timed region; when a step is tens of
+    # microseconds the event packets themselves open gaps between the launches, so only every 8th step is timed
+    ev_stride = 1 if total_cost >= 1e9 else 8
+    for i_ in range(args.steps):
+        step(events if i_ % ev_stride == 0 else None)
+    t_enqueued = time.perf_counter() - t0  # host time to enqueue the K steps (a run is host-bound if this is ~ dt)
     gathered = gather()
     barrier()
     dt = time.perf_counter() - t0
@@ -399,22 +484,27 @@ def main():
 
     # events come in (start, stop) pairs around each contiguous group of dominant-kernel launches
     dom_ms = sum(events[i].elapsed_time(events[i + 1]) for i in range(0, len(events), 2))
-    dom_bytes = sum(b.bytes for b in dom) * args.steps
-    n_launch = max((len(dom) if args.per_tensor else -(-len(dom) // 32)) * args.steps, 1)
+    timed_steps = len(range(0, args.steps, ev_stride))
+    dom_bytes = sum(b.bytes for b in dom) * timed_steps
+    n_launch = max((len(dom) if args.per_tensor else -(-len(dom) // (48 if mixed is not None else 32))) * timed_steps, 1)
 
     if rank == 0:
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes of THIS bench at THIS launch
+        # size (tools/profile_bench_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 runs, the read side
+        # corrected by the known-size calibration read of the same run); null when the record is for another
+        # workload / launch size
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_bench.json")
+        alg_per_launch = dom_bytes / n_launch
         if os.path.isfile(tpath):
-            # HBM bytes per launch from the committed PMC passes (tools/profile_pmc.sh: FETCH_SIZE and
-            # WRITE_SIZE in separate runs, read side corrected x2 by the dword-per-lane calibration
-            # kernel), scaled from the probe's launch size to this run's algorithmic bytes per launch
             try:
-                # the multi-tensor kernel runs the same per-group code as k_energy_codelet: same traffic
-                rec = json.load(open(tpath)).get("k_energy_codelet_%d_%d_0_false" % (dom_edge, dom_edge), {})
-                if rec.get("hbm_over_alg"):
-                    traffic = rec["hbm_over_alg"] * dom_bytes / n_launch
+                want = ("k_energy_codelet_mixed" if mixed is not None else kernel_name(dom_edge, args.per_tensor)).split(" ")[0].split("<")[0]
+                for kname, rec in json.load(open(tpath)).get("kernels", {}).items():
+                    if kname.split("<")[0] == want and rec.get("alg_bytes_per_launch") and \
+                            abs(rec["alg_bytes_per_launch"] - alg_per_launch) <= 0.01 * alg_per_launch:
+                        if mixed is not None or ("<%d, %d" % (dom_edge, dom_edge)) in kname or "tile2d" in kname or "split" in kname:
+                            traffic = rec["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
         res = {
@@ -425,14 +515,16 @@ def main():
             "config": {"workload": "%s hooked feature maps (%d tensors, %d maps/sample: %s), batch %d, limit=steps"
                                    % (args.net, len(points), sum(chans), shape_summary, N),
                        "global_batch": N, "sharding": "layer-sharded (LPT on bytes), 1 all-gather" if world > 1 else "none",
-                       "launch_mode": "per-tensor" if args.per_tensor else "one launch per tile shape",
+                       "launch_mode": "per-tensor" if args.per_tensor else ("one launch for all tile shapes" if mixed is not None
+                                                                               else "one launch per tile shape"),
                        "units_rank0": len(bound), "load_imbalance": (max(load) / (sum(load) / world)) if world > 1 else 1.0},
             "GB_s_whole_step": total_cost * args.steps / dt / 1e9,
+            "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "roofline": {"bound": "hbm",
-                         "kernel": kernel_name(dom_edge, args.per_tensor),
+                         "kernel": "k_energy_codelet_mixed (edges 2..32)" if mixed is not None else kernel_name(dom_edge, args.per_tensor),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launches": n_launch, "avg_launch_us": dom_ms / n_launch * 1e3,
+                         "launches": n_launch, "timed_steps": timed_steps, "avg_launch_us": dom_ms / n_launch * 1e3,
                          "alg_bytes_per_launch": dom_bytes / n_launch},
             "parity_check_rel_err": rel, "dead_channels_not_plus_zero": dead_bad,
         }

@@ -18,9 +18,10 @@ from .ops import (  # noqa: F401
     ALGO_TILE2D,
     batch_sum,
     dct2d,
+    energy_mixed,
     energy_multi,
     energy_nc,
     has_codelet,
 )
 
-__all__ = ["energy_nc", "energy_multi", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE", "ALGO_TILE2D"]
+__all__ = ["energy_nc", "energy_multi", "energy_mixed", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE", "ALGO_TILE2D"]

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dcts_batch_sum_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "dcts_running_mean_update_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.c_float, _vp]),
     "dcts_energy_multi_f32": (ctypes.c_int, [_vp, _i32, _i64, _i64, _i32, _vp, _sz, _vp]),
+    "dcts_energy_mixed_f32": (ctypes.c_int, [_vp, _i32, _vp, _sz, _vp]),
     "dcts_running_mean_update_multi_f32": (ctypes.c_int, [_vp, _i32, _vp]),
     "dcts_debug_stream_read_f32": (ctypes.c_int, [_vp, _i64, _vp, _vp]),
 }
@@ -48,6 +49,11 @@ class TensorItem(ctypes.Structure):
     """struct dcts_tensor_item (include/dctscore.h)."""
     _fields_ = [("x", _vp), ("out_nc", _vp), ("N", _i64), ("C_total", _i64), ("strideN", _i64), ("strideC", _i64),
                 ("c_begin", _i32), ("c_count", _i32)]
+
+
+class ShapedItem(ctypes.Structure):
+    """struct dcts_shaped_item (include/dctscore.h)."""
+    _fields_ = [("t", TensorItem), ("H", _i64), ("W", _i64), ("pad_front_if_odd", _i32), ("reserved", _i32)]
 
 
 class DctScoreError(RuntimeError):

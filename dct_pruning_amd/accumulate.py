@@ -92,21 +92,21 @@ class DeviceBatchAccumulator:
 
     def _score_pending_tensors(self):
         from . import ops
-        groups = {}
-        for key, (x, cb, cc, pad, version) in self.pending_x.items():
+        keys = list(self.pending_x)
+        for key in keys:
+            x, cb, cc, pad, version = self.pending_x[key]
             if x._version != version:
                 self.pending_x.clear()
                 raise RuntimeError(
                     "deferred scoring: the tensor hooked at %r was modified in place after its hook fired "
                     "(version %d -> %d); scores would be those of the overwritten data. Run without "
                     "--deferred / deferred=False for this network." % (key, version, x._version))
-            groups.setdefault((x.shape[2], x.shape[3], bool(pad)), []).append(key)
-        for (h, w, pad), keys in groups.items():
-            outs = ops.energy_multi([self.pending_x[k][:3] for k in keys], pad_front_if_odd=pad)
-            for k, e in zip(keys, outs):
-                if k not in self.state:
-                    self.state[k] = [torch.zeros(e.shape[1], dtype=torch.float32, device=self.device), 0.0]
-                self.pending[k] = e
+        # every pending tensor in ONE call: small tiles of all shapes share a launch (dcts_energy_mixed_f32)
+        outs = ops.energy_mixed([self.pending_x[k][:4] for k in keys])
+        for k, e in zip(keys, outs):
+            if k not in self.state:
+                self.state[k] = [torch.zeros(e.shape[1], dtype=torch.float32, device=self.device), 0.0]
+            self.pending[k] = e
         self.pending_x.clear()
 
     def flush(self):

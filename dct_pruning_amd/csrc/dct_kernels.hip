@@ -46,6 +46,7 @@ int dispatch_codelet(int store, int HP, int WP, int pad, const void* geom, float
 int dispatch_codelet_dma(int N, const void* geom, float* out, hipStream_t st);
 int dispatch_codelet_multi(int HP, int pad, const void* multi_geom, hipStream_t st);
 int dispatch_lane(int n, const void* multi_geom, hipStream_t st);
+int dispatch_codelet_mixed(const void* mixed_geom, hipStream_t st);
 int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStream_t st);
 int dispatch_fused(int N, const void* tile_batch, hipStream_t st);
 int dispatch_fused2(int N, const void* tile_batch, hipStream_t st);
@@ -258,6 +259,70 @@ __global__ __launch_bounds__((64 * CodeletCfg<HP, WP>::WAVES)) void k_energy_cod
     t = __builtin_amdgcn_readfirstlane(t);
     const MultiItem& item = mg.it[t];
     codelet_group<HP, WP, PAD, false>(item.g, item.out, grp - item.group_begin, my, g1, c, g2, k, act1, act2);
+  }
+}
+
+// Tensors of DIFFERENT small tile shapes in one launch (edges 2, 4, 8, 16, 32: every hooked tensor of
+// the CIFAR nets). VGG-16-bn at batch 256 is 187 MB of activations in five tile shapes: five launches
+// plus the running-mean update were 58 us, launch ramps and tails costing as much as the work. The
+// groups of all tensors form one index space (a group = floor(64 / edge) maps of ITS tensor's shape);
+// a wave switches on the shape of the tensor its group belongs to and runs that shape's codelet
+// group: the same code as k_energy_codelet, results bit for bit those of one call per tensor.
+constexpr int kMixedItems = 48;
+struct MixedGeom {
+  MultiItem it[kMixedItems];
+  long long total_groups;
+  int count;
+};
+#define DCTS_MIXED_SIZES(X) X(2) X(4) X(8) X(16) X(32)
+constexpr bool mixed_has(int e) {
+#define DCTS_CASE(N) \
+  if (e == N) return true;
+  DCTS_MIXED_SIZES(DCTS_CASE)
+#undef DCTS_CASE
+  return false;
+}
+constexpr int mixed_slab_floats() {
+  int m = 0;
+#define DCTS_CASE(N) \
+  if (CodeletCfg<N, N>::WAVE_LDS > m) m = CodeletCfg<N, N>::WAVE_LDS;
+  DCTS_MIXED_SIZES(DCTS_CASE)
+#undef DCTS_CASE
+  return m;
+}
+constexpr int kMixedWaves = 4;
+
+template <int E>
+__device__ __forceinline__ void mixed_group(const MultiItem& item, long long grp, float* my, int lane) {
+  using Cfg = CodeletCfg<E, E>;
+  const int g1 = lane / E, c = lane - g1 * E;  // square tile: pass-1 and pass-2 roles coincide
+  const bool act = g1 < Cfg::G;
+  codelet_group<E, E, 0, false>(item.g, item.out, grp, my, g1, c, g1, c, act, act);
+}
+
+__global__ __launch_bounds__((64 * kMixedWaves)) void k_energy_codelet_mixed(MixedGeom mg) {
+  __shared__ float slab[kMixedWaves][mixed_slab_floats()];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* my = slab[wave];
+  const long long wave_gid = (long long)blockIdx.x * kMixedWaves + wave;
+  const long long nwaves = (long long)gridDim.x * kMixedWaves;
+  int t = 0;
+  for (long long grp = wave_gid; grp < mg.total_groups; grp += nwaves) {
+    while (t + 1 < mg.count && grp >= mg.it[t + 1].group_begin) ++t;  // wave-uniform, monotone
+    t = __builtin_amdgcn_readfirstlane(t);
+    const MultiItem& item = mg.it[t];
+    const long long local = grp - item.group_begin;
+    switch (__builtin_amdgcn_readfirstlane(item.g.H)) {
+#define DCTS_CASE(N)                          \
+  case N:                                     \
+    mixed_group<N>(item, local, my, lane);    \
+    break;
+      DCTS_MIXED_SIZES(DCTS_CASE)
+#undef DCTS_CASE
+      default:
+        break;
+    }
   }
 }
 
@@ -1668,6 +1733,16 @@ __device__ __forceinline__ float strip_batch_sum(const float* __restrict__ e, lo
   float s = 0.f;
   if (j < C) {
     long long n = slice;
+    // sixteen loads in flight per lane and round trip (a batch of 256 samples is ONE round trip: the
+    // kernel is pure latency, 3.8 us with four loads per trip); the additions keep their order
+#pragma unroll 1
+    for (; n + 15 * kSumSl < N; n += 16 * kSumSl) {
+      float a[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] = e[(n + i * kSumSl) * C + j];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += a[i];
+    }
 #pragma unroll 1
     for (; n + 3 * kSumSl < N; n += 4 * kSumSl) {
       const float a0 = e[n * C + j], a1 = e[(n + kSumSl) * C + j];
@@ -2211,6 +2286,21 @@ int launch_lane(const MultiGeom& mg, hipStream_t st) {
 }  // namespace
 #if DCTS_PART(1)
 namespace dctsi {
+int dispatch_codelet_mixed(const void* mixed_geom, hipStream_t st) {
+  const MixedGeom& mg = *static_cast<const MixedGeom*>(mixed_geom);
+  static const int per_cu = [] {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_energy_codelet_mixed, 64 * kMixedWaves, 0) != hipSuccess || n < 1)
+      n = 1;
+    return n;
+  }();
+  long long blocks = (mg.total_groups + kMixedWaves - 1) / kMixedWaves;
+  const long long cap = (long long)num_cus() * per_cu;  // one residency of persistent waves
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_energy_codelet_mixed, dim3((unsigned)blocks), dim3(64 * kMixedWaves), 0, st, mg);
+  return (int)hipGetLastError();
+}
 int dispatch_lane(int n, const void* multi_geom, hipStream_t st) {
   const MultiGeom& mg = *static_cast<const MultiGeom*>(multi_geom);
 
@@ -2606,6 +2696,88 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
     if (rc) return rc;
   }
   return flush();
+}
+
+int dcts_energy_mixed_f32(const dcts_shaped_item* items, int32_t count, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!items) return DCTS_E_NULL;
+  if (count <= 0) return DCTS_E_SHAPE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int32_t i = 0; i < count; ++i) {
+    const dcts_tensor_item& t = items[i].t;
+    if (!t.x || !t.out_nc) return DCTS_E_NULL;
+    if (t.N <= 0 || t.C_total <= 0 || items[i].H <= 0 || items[i].W <= 0) return DCTS_E_SHAPE;
+    if (t.c_count <= 0 || t.c_begin < 0 || (int64_t)t.c_begin + t.c_count > t.C_total) return DCTS_E_CHANNELS;
+    if ((reinterpret_cast<uintptr_t>(t.x) & 3) || (reinterpret_cast<uintptr_t>(t.out_nc) & 3)) return DCTS_E_ALIGN;
+  }
+  auto eligible = [&](const dcts_shaped_item& it) {
+    return it.H == it.W && mixed_has((int)it.H) && !(it.pad_front_if_odd && (it.H % 2 != 0));
+  };
+  // 1. every small-tile tensor, whatever its shape, in one launch per kMixedItems of them
+  MixedGeom mg;
+  int n = 0;
+  long long groups = 0;
+  auto flush = [&]() -> int {
+    if (!n) return DCTS_OK;
+    for (int i = n; i < kMixedItems; ++i) mg.it[i] = mg.it[0];
+    mg.total_groups = groups;
+    mg.count = n;
+    n = 0;
+    groups = 0;
+    return dctsi::dispatch_codelet_mixed(&mg, st);
+  };
+  for (int32_t i = 0; i < count; ++i) {
+    if (!eligible(items[i])) continue;
+    const dcts_tensor_item& t = items[i].t;
+    MapGeom& g = mg.it[n].g;
+    g.x = t.x;
+    g.nmaps = t.N * (int64_t)t.c_count;
+    g.strideN = t.strideN;
+    g.strideC = t.strideC;
+    g.strideH = items[i].W;
+    g.c_count = t.c_count;
+    g.c_begin = t.c_begin;
+    g.H = (int)items[i].H;
+    g.W = (int)items[i].W;
+    g.contiguous = (t.N == 1 || t.strideN == (int64_t)t.c_count * t.strideC) ? 1 : 0;
+    mg.it[n].out = t.out_nc;
+    mg.it[n].group_begin = groups;
+    const int G = 64 / (int)items[i].H;
+    groups += (g.nmaps + G - 1) / G;
+    if (++n == kMixedItems) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+  }
+  int rc = flush();
+  if (rc) return rc;
+  // 2. the rest shape by shape (first occurrence order), through dcts_energy_multi_f32
+  dcts_tensor_item buf[64];
+  for (int32_t i = 0; i < count; ++i) {
+    if (eligible(items[i])) continue;
+    bool seen = false;
+    for (int32_t k = 0; k < i && !seen; ++k)
+      seen = !eligible(items[k]) && items[k].H == items[i].H && items[k].W == items[i].W &&
+             (items[k].pad_front_if_odd != 0) == (items[i].pad_front_if_odd != 0);
+    if (seen) continue;
+    int m = 0;
+    for (int32_t k = i; k < count; ++k) {
+      if (eligible(items[k]) || items[k].H != items[i].H || items[k].W != items[i].W ||
+          (items[k].pad_front_if_odd != 0) != (items[i].pad_front_if_odd != 0))
+        continue;
+      buf[m++] = items[k].t;
+      if (m == 64) {
+        rc = dcts_energy_multi_f32(buf, m, items[i].H, items[i].W, items[i].pad_front_if_odd, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        m = 0;
+      }
+    }
+    if (m) {
+      rc = dcts_energy_multi_f32(buf, m, items[i].H, items[i].W, items[i].pad_front_if_odd, workspace, workspace_bytes, stream);
+      if (rc) return rc;
+    }
+  }
+  return DCTS_OK;
 }
 
 int dcts_running_mean_update_multi_f32(const dcts_update_desc* descs, int32_t count, void* stream) {

@@ -134,3 +134,41 @@ def energy_multi(items, pad_front_if_odd=False):
         _lib.check(lib.dcts_energy_multi_f32(arr, len(items), H, W, 1 if pad_front_if_odd else 0,
                                              ws.data_ptr(), ws.numel(), stream))
     return outs
+
+
+def energy_mixed(items):
+    """energy_nc for tensors of ANY tile shapes in one call (dcts_energy_mixed_f32): small square tiles
+    (edges 2..32) of all shapes share one launch, the rest go shape by shape.
+
+    items: list of (x, c_begin, c_count, pad_front_if_odd). Returns the list of [N, c_count] outputs;
+    the tensors must stay alive until the stream has run."""
+    lib = _lib.load()
+    if not items:
+        return []
+    dev = items[0][0].device
+    arr = (_lib.ShapedItem * len(items))()
+    outs, keep = [], []
+    need = 0
+    for i, (x, c_begin, c_count, pad) in enumerate(items):
+        _check_input(x)
+        if x.device != dev:
+            raise ValueError("energy_mixed needs tensors on one device")
+        H, W = x.shape[2], x.shape[3]
+        if x.stride(3) != 1 or x.stride(2) != W:
+            x = x.contiguous()
+        c_begin, c_count = _slice(x, c_begin, c_count)
+        out = torch.empty((x.shape[0], c_count), dtype=torch.float32, device=dev)
+        keep.append(x)
+        outs.append(out)
+        t = arr[i].t
+        t.x, t.out_nc = x.data_ptr(), out.data_ptr()
+        t.N, t.C_total = x.shape[0], x.shape[1]
+        t.strideN, t.strideC = x.stride(0), x.stride(1)
+        t.c_begin, t.c_count = c_begin, c_count
+        arr[i].H, arr[i].W, arr[i].pad_front_if_odd = H, W, 1 if pad else 0
+        need = max(need, lib.dcts_workspace_bytes(x.shape[0], c_count, H, W))
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ws = _workspace(dev, stream, need)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dcts_energy_mixed_f32(arr, len(items), ws.data_ptr(), ws.numel(), stream))
+    return outs

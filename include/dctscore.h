@@ -167,6 +167,22 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
                           int32_t pad_front_if_odd, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same for tensors of DIFFERENT tile shapes: every hooked tensor of a forward pass in one call.
+ * Tensors with square tiles of edge 2, 4, 8, 16 or 32 (every hook point of the reference's CIFAR nets:
+ * VGG-16-bn, ResNet-56/110, DenseNet-40, GoogLeNet) share ONE launch per 48 of them, whatever their
+ * shapes; the others are grouped by shape as dcts_energy_multi_f32 does. Results are those of one
+ * dcts_energy_f32 call per tensor, bit for bit. `workspace` must cover the largest item that needs one.
+ */
+typedef struct dcts_shaped_item {
+  dcts_tensor_item t;
+  int64_t H, W;
+  int32_t pad_front_if_odd;
+  int32_t reserved;
+} dcts_shaped_item;
+int dcts_energy_mixed_f32(const dcts_shaped_item* items, int32_t count, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/*
  * Device-side form of the running-mean update of get_feature_hook, utils/common.py:273-277:
  *   c = sum_n energy_nc[n, :]
  *   feature_result = (feature_result * total_before + c) / (total_before + N)

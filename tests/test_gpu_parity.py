@@ -339,3 +339,29 @@ def test_energy_multi_matches_single_calls(n, pad):
         ref = dpa.energy_nc(x, c_begin=cb, c_count=cc, pad_front_if_odd=pad)
         assert torch.equal(got, ref)
         check(x.cpu(), got, c_begin=cb, c_count=cc, pad_front_if_odd=pad)
+
+
+def test_mixed_shape_launch_is_bitwise_equal_to_per_tensor_calls():
+    """dcts_energy_mixed_f32: tensors of different small tile shapes in one launch (the CIFAR nets'
+    hook points), channel slices and odd-pad items included; results must be those of one
+    dcts_energy_f32 call per tensor, bit for bit."""
+    items = []
+    for i, (n, c, h) in enumerate([(32, 64, 32), (32, 64, 16), (32, 128, 16), (32, 128, 8), (32, 256, 8), (32, 256, 4),
+                                   (32, 512, 4), (32, 512, 2), (5, 3, 32), (1, 1, 2), (7, 36, 16), (3, 20, 9), (2, 8, 56),
+                                   (2, 6, 72), (4, 16, 7)]):
+        x = synth(n, c, h, h, 700 + i).cuda()
+        if i == 10:
+            items.append((x, c - 12, 12, True))      # DenseNet-style channel slice, cv2 flag on an even tile
+        elif i == 11:
+            items.append((x, 0, None, True))         # odd tile with the front pad: not a mixed-launch shape
+        else:
+            items.append((x, 0, None, False))
+    outs = dpa.energy_mixed(items)
+    for (x, cb, cc, pad), got in zip(items, outs):
+        want = dpa.energy_nc(x, cb, cc, pad)
+        assert got.shape == want.shape
+        assert torch.equal(got, want)
+    # more tensors than one launch takes (48)
+    many = [(synth(4, 8 + (i % 5), 8, 8, 900 + i).cuda(), 0, None, False) for i in range(61)]
+    for (x, _, _, _), got in zip(many, dpa.energy_mixed(many)):
+        assert torch.equal(got, dpa.energy_nc(x))
