@@ -22,6 +22,7 @@ SIGNATURES = {
     "dcts_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "dcts_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "dcts_has_codelet": (ctypes.c_int, [_i64, _i64]),
+    "dcts_workspace_invalidate": (None, [_vp]),
     "dcts_energy_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                        _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dcts_energy_f32_ex": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,

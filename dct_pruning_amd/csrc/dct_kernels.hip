@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "../../include/dctscore.h"
 #include "codelet_sizes.h"
 #include "dct_codelets.hpp"
@@ -2398,6 +2400,41 @@ int dispatch_tile_family(int fam, int HP, const TileBatch& tb, hipStream_t st) {
   }
 }
 
+// The direct kernel's basis tables live at the head of the caller's workspace. They are built once per
+// (workspace, stream, H', W') and reused by later calls: the library remembers - on the host, nothing is read
+// back - what it last left in a workspace, and forgets it whenever another of its paths writes there (the
+// split path's intermediate, the coefficient path's leaf outputs) or the caller says so
+// (dcts_workspace_invalidate). Same stream only: that is what orders the build before the reuse.
+struct BasisSlot {
+  void* ws;
+  void* stream;
+  int HP, WP;
+};
+constexpr int kBasisSlots = 16;
+BasisSlot g_basis[kBasisSlots] = {};
+int g_basis_next = 0;
+std::mutex g_basis_mu;
+
+bool basis_cached(void* ws, void* stream, int HP, int WP) {
+  std::lock_guard<std::mutex> lk(g_basis_mu);
+  for (const BasisSlot& b : g_basis)
+    if (b.ws == ws && b.stream == stream && b.HP == HP && b.WP == WP) return true;
+  return false;
+}
+void basis_forget(void* ws) {
+  if (!ws) return;
+  std::lock_guard<std::mutex> lk(g_basis_mu);
+  for (BasisSlot& b : g_basis)
+    if (b.ws == ws) b = BasisSlot{};
+}
+void basis_remember(void* ws, void* stream, int HP, int WP) {
+  std::lock_guard<std::mutex> lk(g_basis_mu);
+  for (BasisSlot& b : g_basis)
+    if (b.ws == ws) b = BasisSlot{};  // one shape per workspace: the tables overwrite each other
+  g_basis[g_basis_next] = BasisSlot{ws, stream, HP, WP};
+  g_basis_next = (g_basis_next + 1) % kBasisSlots;
+}
+
 template <bool STORE>
 int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_t strideN,
         int64_t strideC, int64_t strideH, int64_t strideW, int32_t c_begin, int32_t c_count,
@@ -2484,6 +2521,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       const SplitWs sws = split_ws(g.nmaps, (int)HP);
       if (!workspace || workspace_bytes < sws.total) return DCTS_E_WORKSPACE;
       if (reinterpret_cast<uintptr_t>(workspace) & 15) return DCTS_E_ALIGN;  // pass 2 stages the intermediate the same way
+      basis_forget(workspace);
       return dispatch_split((int)HP, g, out, workspace, st);
     }
   } else {
@@ -2499,6 +2537,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       if (ws_maps < 1 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return DCTS_E_WORKSPACE;
       const float* x0 = x + (long long)c_begin * strideC;
       float* scratch = reinterpret_cast<float*>(workspace);
+      basis_forget(workspace);
       if (algo == DCTS_ALGO_TILE2D) return dctsi::dispatch_tile2d_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
       if (has_fused2(HP)) return dctsi::dispatch_fused2_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
       return dctsi::dispatch_fused_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
@@ -2512,8 +2551,11 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   float* CHt = reinterpret_cast<float*>(wsp + ws.off_ch);
   float* CWt = reinterpret_cast<float*>(wsp + ws.off_cw);
   float* T = reinterpret_cast<float*>(wsp + ws.off_t);
-  hipLaunchKernelGGL(k_basis, dim3((unsigned)((HP * HP + 255) / 256)), dim3(256), 0, st, CHt, (int)HP);
-  hipLaunchKernelGGL(k_basis, dim3((unsigned)((WP * WP + 255) / 256)), dim3(256), 0, st, CWt, (int)WP);
+  if (!basis_cached(workspace, stream, (int)HP, (int)WP)) {
+    hipLaunchKernelGGL(k_basis, dim3((unsigned)((HP * HP + 255) / 256)), dim3(256), 0, st, CHt, (int)HP);
+    hipLaunchKernelGGL(k_basis, dim3((unsigned)((WP * WP + 255) / 256)), dim3(256), 0, st, CWt, (int)WP);
+    if (hipGetLastError() == hipSuccess) basis_remember(workspace, stream, (int)HP, (int)WP);
+  }
   hipLaunchKernelGGL((k_energy_direct<STORE>), dim3((unsigned)ws.grid), dim3(kDirectThreads), 0, st,
                      g, pad, CHt, CWt, T, out);
   return (int)hipGetLastError();
@@ -2555,6 +2597,8 @@ size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W) {
 }
 
 int dcts_has_codelet(int64_t H, int64_t W) { return has_codelet(H, W) ? 1 : 0; }
+
+void dcts_workspace_invalidate(void* workspace) { basis_forget(workspace); }
 
 int dcts_energy_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
                        int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,

@@ -113,6 +113,11 @@ int dcts_energy_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, in
                        float* out_nc, void* workspace, size_t workspace_bytes, void* stream,
                        int32_t algo);
 
+/* The library keeps immutable basis tables at the head of a workspace between calls (built once per
+ * workspace, stream and tile shape; remembered on the host, nothing is read back). A caller that writes into a
+ * workspace itself, or frees it and allocates another at the same address, says so here first. */
+void dcts_workspace_invalidate(void* workspace);
+
 /* 1 if DCTS_ALGO_CODELET has a kernel for an (H, W) tile (sizes AFTER the odd pad). */
 int dcts_has_codelet(int64_t H, int64_t W);
 

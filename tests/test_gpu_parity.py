@@ -115,12 +115,38 @@ def test_pipelined_sizes(n):
         got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_PIPE)
         check(x, got)
         assert torch.equal(got, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_PIPE))  # bit-reproducible
-        assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
+        if n not in TILE2D:
+            assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
     dead = synth(1, 300, n, n, 99)
     dead[0, ::7] = 0.0  # dead channels: exactly +0.0
     got = dpa.energy_nc(dead.cuda(), algo=dpa.ALGO_PIPE).cpu()
     assert (got[0, ::7] == 0).all() and not torch.signbit(got[0, ::7]).any()
     check(dead, got)
+
+
+TILE2D = [224]
+
+
+@pytest.mark.parametrize("n", TILE2D)
+def test_tile2d_sizes(n):
+    """2-D radix-8 split kernel (tile2d.hip), AUTO for 224x224. Map counts so that workgroups run 1, 2, 3 and
+    4+ maps (the next map's loads are issued one map ahead; the last map reloads itself) and fewer maps than
+    workgroups; several tensors in one launch; dead channels; bit-reproducible; against the pipelined kernel."""
+    for nmaps, seed in [(1, 0), (3, 1), (256, 2), (257, 3), (512, 4), (600, 5), (800, 6)]:
+        x = synth(1, nmaps, n, n, 270 + n + seed)
+        got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_TILE2D)
+        check(x, got)
+        assert torch.equal(got, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_TILE2D))  # bit-reproducible
+        assert torch.equal(got, dpa.energy_nc(x.cuda()))  # AUTO picks it
+        assert rel_err(got.cpu(), dpa.energy_nc(x.cuda(), algo=dpa.ALGO_PIPE).cpu()) <= 1e-5
+    dead = synth(1, 300, n, n, 99)
+    dead[0, ::7] = 0.0  # dead channels: exactly +0.0
+    got = dpa.energy_nc(dead.cuda()).cpu()
+    assert (got[0, ::7] == 0).all() and not torch.signbit(got[0, ::7]).any()
+    check(dead, got)
+    tensors = [synth(2, c, n, n, 500 + c).cuda() for c in (3, 16, 1, 64)]
+    for x, e in zip(tensors, dpa.energy_multi([(x, 0, None) for x in tensors])):
+        assert torch.equal(e, dpa.energy_nc(x))  # one launch for all of them == one call each
 
 
 def test_split_chunking_many_maps():
@@ -365,3 +391,24 @@ def test_mixed_shape_launch_is_bitwise_equal_to_per_tensor_calls():
     many = [(synth(4, 8 + (i % 5), 8, 8, 900 + i).cuda(), 0, None, False) for i in range(61)]
     for (x, _, _, _), got in zip(many, dpa.energy_mixed(many)):
         assert torch.equal(got, dpa.energy_nc(x))
+
+
+def test_direct_kernel_basis_tables_are_cached_safely():
+    """The direct kernel builds its basis tables once per (workspace, stream, shape); shape changes and other
+    users of the same workspace (the two-launch split path) must not leave stale tables behind."""
+    def check(shape, algo=dpa.ALGO_DIRECT):
+        x = synth(2, 3, shape[0], shape[1], 31 + shape[0])
+        got = dpa.energy_nc(x.cuda(), algo=algo).cpu()
+        ref = torch.from_numpy(orc.energy_nc_f64(x)) if max(shape) > 64 else orc.energy_nc(x)
+        assert rel_err(got, ref) <= RTOL, shape
+
+    check((24, 24))
+    check((24, 24))          # cached tables
+    check((30, 20))          # other shape, same workspace
+    check((24, 24))          # back: rebuilt
+    check((72, 72), dpa.ALGO_SPLIT)   # the split path's intermediate overwrites the head of the workspace
+    check((24, 24))
+    x = synth(1, 2, 24, 24, 5, dead=False)
+    got = dpa.dct2d(x.cuda(), algo=dpa.ALGO_DIRECT).cpu().numpy()
+    assert np.abs(got - orc.dct_2d_f64(x.numpy())).max() <= 2e-6 * np.abs(got).max()
+    check((24, 24))
