@@ -22,6 +22,7 @@ from .ops import (  # noqa: F401
     energy_multi,
     energy_nc,
     has_codelet,
+    weighted_energy_nc,
 )
 
-__all__ = ["energy_nc", "energy_multi", "energy_mixed", "dct2d", "batch_sum", "has_codelet", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE", "ALGO_TILE2D"]
+__all__ = ["energy_nc", "energy_multi", "energy_mixed", "dct2d", "batch_sum", "has_codelet", "weighted_energy_nc", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE", "ALGO_TILE2D"]

@@ -31,6 +31,9 @@ SIGNATURES = {
                                       _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dcts_dct2d_f32_ex": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                          _i32, _i32, _i32, _vp, _vp, _sz, _vp, _i32]),
+    "dcts_weighted_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
+    "dcts_weighted_energy_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                                _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "dcts_batch_sum_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "dcts_running_mean_update_f32": (ctypes.c_int, [_vp, _i64, _i64, _vp, ctypes.c_float, _vp]),
     "dcts_energy_multi_f32": (ctypes.c_int, [_vp, _i32, _i64, _i64, _i32, _vp, _sz, _vp]),

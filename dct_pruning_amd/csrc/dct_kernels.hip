@@ -1810,6 +1810,26 @@ __global__ __launch_bounds__(kSumCh * kSumSl) void k_running_mean_multi(UpdateBa
   }
 }
 
+// Score variant in the coefficient domain: out[m] = sum_{u,v} weights[u,v] * coeff[m][u][v]^2.
+// One wave per map over dense [HW] coefficient tiles; lanes stride the tile, fixed-order wave sum.
+__global__ __launch_bounds__(256) void k_weighted_energy(const float* __restrict__ coeff, const float* __restrict__ weights,
+                                                         long long nmaps, int hw, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long m = wave; m < nmaps; m += nwaves) {
+    const float* c = coeff + m * hw;
+    float e = 0.f;
+    for (int i = lane; i < hw; i += 64) {
+      const float v = c[i];
+      e = fmaf(weights[i] * v, v, e);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) e += __shfl_down(e, off, 64);
+    if (lane == 0) out[m] = e;
+  }
+}
+
 // PMC calibration aid: streams n floats with the codelet kernels' access width (one dword per
 // lane, consecutive lanes consecutive addresses) so FETCH_SIZE can be compared with a known
 // byte count in this exact pattern (MI355X_MICROARCH.md, HBM section: widths other than
@@ -2632,6 +2652,65 @@ int dcts_dct2d_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_
                    void* workspace, size_t workspace_bytes, void* stream) {
   return run<true>(x, N, C_total, H, W, strideN, strideC, strideH, strideW, c_begin, c_count,
                    pad_front_if_odd, out_coeff, workspace, workspace_bytes, stream, DCTS_ALGO_AUTO);
+}
+
+size_t dcts_weighted_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W) {
+  if (N <= 0 || C_count <= 0 || H <= 0 || W <= 0) return 0;
+  // coefficients of a chunk of maps + what the coefficient path itself needs for that chunk
+  const int64_t HP = H + 1, WP = W + 1;
+  const long long tile = (long long)HP * WP * 4;
+  long long chunk = (256LL << 20) / tile;  // 256 MiB of coefficients per chunk at most
+  if (chunk < 1) chunk = 1;
+  if (chunk > N * C_count) chunk = N * C_count;
+  return align_up((size_t)(chunk * tile), 256) + align_up((size_t)(chunk * tile), 256) + dcts_workspace_bytes(N, C_count, H, W);
+}
+
+int dcts_weighted_energy_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_t strideN,
+                             int64_t strideC, int64_t strideH, int64_t strideW, int32_t c_begin, int32_t c_count,
+                             int32_t pad_front_if_odd, const float* weights, float* out_nc, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (!x || !out_nc || !weights) return DCTS_E_NULL;
+  if (N <= 0 || C_total <= 0 || H <= 0 || W <= 0) return DCTS_E_SHAPE;
+  if (c_count <= 0 || c_begin < 0 || (int64_t)c_begin + c_count > C_total) return DCTS_E_CHANNELS;
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return workspace ? DCTS_E_ALIGN : DCTS_E_WORKSPACE;
+  const int pad = (pad_front_if_odd && (H % 2 != 0)) ? 1 : 0;
+  const int64_t HP = H + pad, WP = W + pad;
+  const long long tile = (long long)HP * WP * 4;
+  // workspace = [coefficients of a chunk][scratch the coefficient path may use]
+  const size_t inner_min = dcts_workspace_bytes(1, 1, H, W);
+  if (workspace_bytes < (size_t)(2 * tile) + inner_min) return DCTS_E_WORKSPACE;
+  long long chunk = (long long)((workspace_bytes - inner_min) / (size_t)(2 * tile));
+  if (chunk < 1) return DCTS_E_WORKSPACE;
+  const size_t off_inner = align_up((size_t)(chunk * tile), 256);
+  if (off_inner + (size_t)(chunk * tile) > workspace_bytes) --chunk;
+  if (chunk < 1) return DCTS_E_WORKSPACE;
+  char* wsp = reinterpret_cast<char*>(workspace);
+  float* coeff = reinterpret_cast<float*>(wsp);
+  void* inner = wsp + align_up((size_t)(chunk * tile), 256);
+  const size_t inner_bytes = workspace_bytes - align_up((size_t)(chunk * tile), 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // the large-tile kernels where the tensor suits them, else whatever AUTO picks (codelet / direct)
+  // (every inner call covers channels of ONE sample, so the batch stride does not matter)
+  const bool dense = pad == 0 && H == W && strideH == W && strideW == 1 && strideC == H * W && (strideN * 4) % 16 == 0 &&
+                     (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
+  const int algo = (dense && has_tile2d(HP)) ? DCTS_ALGO_TILE2D : (dense && (has_fused(HP) || has_fused2(HP))) ? DCTS_ALGO_FUSED : DCTS_ALGO_AUTO;
+  // maps are taken sample by sample in runs of channels so that a chunk is one strided view of x
+  const long long per_sample = c_count;
+  for (int64_t n = 0; n < N; ++n) {
+    for (long long c0 = 0; c0 < per_sample; c0 += chunk) {
+      const long long nc = (per_sample - c0) < chunk ? (per_sample - c0) : chunk;
+      int rc = run<true>(x + n * strideN, 1, C_total, H, W, strideN, strideC, strideH, strideW, (int32_t)(c_begin + c0), (int32_t)nc,
+                         pad_front_if_odd, coeff, inner, inner_bytes, stream, algo);
+      if (rc) return rc;
+      long long blocks = (nc * 64 + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(k_weighted_energy, dim3((unsigned)blocks), dim3(256), 0, st, coeff, weights, nc, (int)(HP * WP),
+                         out_nc + n * c_count + c0);
+      rc = (int)hipGetLastError();
+      if (rc) return rc;
+    }
+  }
+  return DCTS_OK;
 }
 
 int dcts_batch_sum_f32(const float* energy_nc, int64_t N, int64_t C_count, float* out_c,

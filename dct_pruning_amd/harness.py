@@ -66,6 +66,22 @@ def get_feature_hook_u2net_input(self, input, output):
     _acc.update(_hook_energy("input", input[0]))
 
 
+def make_weighted_feature_hook(weights_for):
+    """Score variant in the coefficient domain (the reference only hints at variants,
+    utils/common.py:268-269): a forward hook with get_feature_hook's signature and accumulation that scores
+    sum_{u,v} w[u,v] * coeff[u,v]^2 instead of sum coeff^2. `weights_for(H, W)` returns the [H, W] weights
+    (any array-like); they are cached per shape on the hooked tensor's device."""
+    cache = {}
+
+    def hook(self, input, output):
+        key = (output.shape[2], output.shape[3], output.device)
+        if key not in cache:
+            cache[key] = torch.as_tensor(weights_for(output.shape[2], output.shape[3]), dtype=torch.float32).to(output.device)
+        _acc.update(ops.weighted_energy_nc(output, cache[key]))
+
+    return hook
+
+
 _HOOKS = {"full": get_feature_hook, "last12": get_feature_hook_densenet, "input": get_feature_hook_u2net_input}
 
 

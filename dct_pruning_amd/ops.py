@@ -175,3 +175,26 @@ def energy_mixed(items):
     with torch.cuda.device(dev):
         _lib.check(lib.dcts_energy_mixed_f32(arr, len(items), ws.data_ptr(), ws.numel(), stream))
     return outs
+
+
+def weighted_energy_nc(x, weights, c_begin=0, c_count=None, pad_front_if_odd=False):
+    """Coefficient-domain score variant: E[n, j] = sum_{u,v} weights[u,v] * dct_2d(x[n, c_begin+j])[u,v]**2.
+    `weights`: [H', W'] fp32 on x's device (H' = H + 1 for an odd H with pad_front_if_odd). All ones gives energy_nc."""
+    _check_input(x)
+    c_begin, c_count = _slice(x, c_begin, c_count)
+    N, C, H, W = x.shape
+    pad = 1 if (pad_front_if_odd and H % 2 == 1) else 0
+    if weights.shape != (H + pad, W + pad) or weights.dtype != torch.float32 or weights.device != x.device:
+        raise ValueError("weights must be a float32 [%d, %d] tensor on %s" % (H + pad, W + pad, x.device))
+    if x.stride(3) != 1 or x.stride(2) < W:
+        x = x.contiguous()
+    weights = weights.contiguous()
+    lib = _lib.load()
+    out = torch.empty((N, c_count), dtype=torch.float32, device=x.device)
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    ws = _workspace(x.device, stream, lib.dcts_weighted_workspace_bytes(N, c_count, H, W))
+    with torch.cuda.device(x.device):
+        _lib.check(lib.dcts_weighted_energy_f32(
+            x.data_ptr(), N, C, H, W, x.stride(0), x.stride(1), x.stride(2), x.stride(3), c_begin, c_count,
+            1 if pad_front_if_odd else 0, weights.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+    return out

@@ -145,6 +145,20 @@ int dcts_dct2d_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int
                       int32_t algo);
 
 /*
+ * Score variant in the coefficient domain (the reference only hints at variants, utils/common.py:268-269;
+ * SURVEY.md §8 f4): out_nc[n, j] = sum_{u,v} weights[u, v] * dct_2d(x[n, c_begin+j], norm='ortho')[u, v]^2,
+ * `weights` a dense [H', W'] fp32 device array (all ones reproduces dcts_energy_f32 up to rounding).
+ * Coefficients come from the same kernels as dcts_dct2d_f32_ex (the large-tile kernels' own coefficient path
+ * for dense 72..320 tiles). Workspace: dcts_weighted_workspace_bytes(), 16-byte aligned.
+ */
+size_t dcts_weighted_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W);
+int dcts_weighted_energy_f32(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
+                             int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
+                             int32_t c_begin, int32_t c_count, int32_t pad_front_if_odd,
+                             const float* weights, float* out_nc, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
+/*
  * Fused batch reduction for benchmarking and for the single-sweep harness:
  *   out_c[j] = sum_n energy[n, j]   (fp32; summation order: 16 interleaved slices, slice s adds
  *   n = s, s+16, s+32, ... in ascending order, then the 16 partial sums are added in slice order.

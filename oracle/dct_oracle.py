@@ -197,3 +197,20 @@ def kept_filters(orifilter_num, rate):
     """Filter count the model constructors derive from a compress rate, e.g.
     models/cifar10/vgg.py:37: int(out_channels * (1 - rate))."""
     return int(orifilter_num * (1 - rate))
+
+
+# ----------------------------------------------------------------------------------------
+# score variant in the coefficient domain (SURVEY.md §8 f4; the reference only hints at variants in
+# comments, utils/common.py:268-269, so there is no reference code to restate: this is the definition
+# dcts_weighted_energy_f32 is tested against)
+# ----------------------------------------------------------------------------------------
+def weighted_energy_nc_f64(x, weights, c_begin=0, c_count=None, pad_front_if_odd=False):
+    """float64: E[n, j] = sum_{u,v} weights[u,v] * dct_2d(x[n, c_begin+j])[u,v]**2 (numpy [N, c_count])."""
+    a = x.detach().cpu().numpy().astype(np.float64)
+    if c_count is None:
+        c_count = a.shape[1] - c_begin
+    a = a[:, c_begin:c_begin + c_count]
+    if pad_front_if_odd and a.shape[2] % 2 != 0:
+        a = np.pad(a, ((0, 0), (0, 0), (1, 0), (1, 0)))
+    d = dct_2d_f64(a)
+    return (np.asarray(weights, dtype=np.float64)[None, None] * d * d).sum(axis=(-2, -1))

@@ -56,3 +56,25 @@ def test_chunked_workspace_gives_the_same_coefficients():
     a = dpa.dct2d(x, algo=dpa.ALGO_FUSED)
     ref = orc.dct_2d_f64(x.cpu().numpy())
     assert np.abs(a.cpu().numpy() - ref).max() <= TOL * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("edge", [8, 9, 32, 56, 72, 224, 288, 24])
+def test_frequency_weighted_score_variant(edge):
+    """dcts_weighted_energy_f32: sum of w[u,v] * coeff^2, against float64; all-ones weights
+    give the plain energy; a low-pass weight is NOT Parseval-equivalent to anything in the spatial domain, so
+    this is the test in which the coefficients themselves matter."""
+    pad = edge % 2 == 1
+    x = synth(2, 5, edge, edge, 600 + edge, dead=True).cuda()
+    hp = edge + (1 if pad else 0)
+    g = torch.Generator().manual_seed(edge)
+    u = torch.arange(hp, dtype=torch.float32)
+    for w in (torch.ones(hp, hp), torch.rand(hp, hp, generator=g), torch.exp(-(u[:, None] + u[None, :]) / (0.25 * hp))):
+        got = dpa.weighted_energy_nc(x, w.cuda(), pad_front_if_odd=pad).cpu().numpy()
+        ref = orc.weighted_energy_nc_f64(x, w.numpy(), pad_front_if_odd=pad)
+        assert np.allclose(got, ref, rtol=2e-5, atol=1e-6 * ref.max())
+        assert (got[:, 5 % x.shape[1]] >= 0).all()
+    ones = dpa.weighted_energy_nc(x, torch.ones(hp, hp).cuda(), pad_front_if_odd=pad)
+    assert torch.allclose(ones, dpa.energy_nc(x, pad_front_if_odd=pad), rtol=1e-5, atol=0)
+    # a channel slice
+    sl = dpa.weighted_energy_nc(x, torch.ones(hp, hp).cuda(), c_begin=2, c_count=2, pad_front_if_odd=pad)
+    assert torch.equal(sl, ones[:, 2:4])

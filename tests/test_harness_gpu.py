@@ -94,3 +94,35 @@ def test_deferred_multi_launch_mode_equals_per_hook(name, tmp_path):
     assert lines == lines0 and sorted(out) == sorted(base)
     for k in base:
         np.testing.assert_allclose(out[k], base[k], rtol=1e-4, atol=1e-6 * float(base[k].max()), err_msg=k)
+
+
+def test_weighted_hook_variant_accumulates_like_the_plain_hook():
+    """harness.make_weighted_feature_hook: all-ones weights reproduce get_feature_hook's scores (same
+    running mean, utils/common.py:271-277); a DC-only weight picks the squared channel sums."""
+    import dct_pruning_amd as dpa
+    from dct_pruning_amd import harness
+    torch.manual_seed(3)
+    conv = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU()).cuda().eval()
+    batches = [torch.randn(4, 3, 16, 16).cuda() for _ in range(3)]
+
+    def scores(hook):
+        harness._acc.reset()
+        h = conv[1].register_forward_hook(hook)
+        with torch.no_grad():
+            for b in batches:
+                conv(b)
+        h.remove()
+        return harness._acc.feature_result.clone()
+
+    plain = scores(harness.get_feature_hook)
+    ones = scores(harness.make_weighted_feature_hook(lambda H, W: torch.ones(H, W)))
+    assert torch.allclose(ones, plain, rtol=1e-5, atol=0)
+
+    def dc_only(H, W):
+        w = torch.zeros(H, W)
+        w[0, 0] = 1.0
+        return w
+    dc = scores(harness.make_weighted_feature_hook(dc_only))
+    with torch.no_grad():
+        want = torch.stack([(conv(b).sum(dim=(-2, -1)) ** 2 / 256.0) for b in batches]).mean(dim=(0, 1))
+    assert torch.allclose(dc.cpu(), want.cpu(), rtol=1e-4, atol=1e-6 * float(want.max()))
