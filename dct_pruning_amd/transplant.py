@@ -4,8 +4,8 @@ score path, vectorised.
 The reference walks the convolutions in order, derives the kept filters of each from its score file
     select_index = np.argsort(imp)[orifilter_num - currentfilter_num:]; select_index.sort()
 and copies weights one scalar slice at a time in Python double / triple loops
-(utils/load_models.py:17-64 for VGG-16-bn, :441-582 for ResNet-50: ~10^7 interpreter-level copies
-for ResNet-50). Here every such loop is one index_select on the output-filter axis, one on the
+(utils/load_models.py:17-64 for VGG-16-bn, :67-143 for the CIFAR ResNets, :385-438 for DenseNet-40,
+:441-582 for ResNet-50: ~10^7 interpreter-level copies for ResNet-50). Here every such loop is one index_select on the output-filter axis, one on the
 input-channel axis (the previous layer's kept filters) and one assignment: same result, bit for
 bit, on whatever device the tensors live on.
 
@@ -19,9 +19,31 @@ Quirks kept because the result must equal the reference's state dict:
     (record_last = False, :506), batch-norm tensors follow the conv's kept filters, and every
     `num_batches_tracked` is copied (:560).
 
+  * CIFAR ResNet-56/110: only `layerX.k.conv1/conv2` weights are transplanted (score files
+    imp_conv2 ... - the counter starts at 1 and is incremented before use, :80, :89); a full-width conv
+    after a pruned one gets its input channels sliced and then RESETS the index (:123); the stem
+    conv and the linear layer come over whole, batch-norm tensors are never touched (:129-141);
+  * DenseNet-40: `last_select_index` starts as an EMPTY LIST, not None (:388), so the "no previous
+    index" branches are unreachable and the first conv copies nothing at all - conv1 keeps the slim
+    model's own weights; after every conv the kept filters are appended at the position the
+    concatenated feature map gives them in the ORIGINAL network (offset cov_id*12 - (cov_id-1)//13*12,
+    :435), restarted after conv1 and after each transition (cov_id 1, 14, 27, :432); neither
+    batch-norm tensors nor the classifier are copied;
+  * GoogLeNet: inside an Inception block only the 3x3 conv and the two 5x5-branch convs lose filters
+    (score files imp_conv<id>_n3x3 / _n5x5, the latter read for both 5x5-branch convs, :264, :313); the
+    four entry convs get their input channels sliced by the previous block's kept list, which is
+    assembled in the order [1x1, pool, 3x3, 5x5] (:233-242, :275-277, :320-322) - not the order
+    torch.cat uses - with offsets from the ORIGINAL filter table; every conv of the net is on the
+    "sketch" list, so no conv bias is ever copied and `pre_layers.0` (never pruned by the constructor)
+    keeps the slim model's own weights; the batch-norms behind pruned convs and `pre_layers.1` are not
+    copied either, the other batch-norms (four tensors, not num_batches_tracked) and the linear layer
+    come over whole (:361-380).
+
 Widths of the pruned networks (what `currentfilter_num` is) follow the model constructors:
-models/cifar10/vgg.py:37 and models/imagenet/resnet.py:8-27 (adapt_channel).
+models/cifar10/vgg.py:37, models/cifar10/resnet.py:5-30 and models/imagenet/resnet.py:8-27 (adapt_channel),
+models/cifar10/densenet.py:71-75, :91-104, models/cifar10/googlenet.py:28-66, :147-149.
 """
+import math
 import os
 
 import numpy as np
@@ -32,6 +54,12 @@ from .masks import select_index
 VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]  # models/cifar10/vgg.py:5
 RESNET50_STAGE_REPEAT = [3, 4, 6, 3]                                                                # models/imagenet/resnet.py:3
 RESNET50_STAGE_OUT = [64] + [256] * 3 + [512] * 4 + [1024] * 6 + [2048] * 3                         # :4
+RESNET_CIFAR_REPEAT = {56: [9, 9, 9], 110: [18, 18, 18]}                                           # models/cifar10/resnet.py:7-12
+DENSENET40_GROWTH, DENSENET40_BLOCK = 12, 12                                                        # models/cifar10/densenet.py:53, :58
+GOOGLENET_FILTERS = [[64, 128, 32, 32], [128, 192, 96, 64], [192, 208, 48, 64], [160, 224, 64, 64], [128, 256, 64, 64],
+                     [112, 288, 64, 64], [256, 320, 128, 128], [256, 320, 128, 128], [384, 384, 128, 128]]  # utils/load_models.py:149-159
+GOOGLENET_BLOCKS = ["inception_a3", "inception_b3", "inception_a4", "inception_b4", "inception_c4", "inception_d4",
+                    "inception_e4", "inception_a5", "inception_b5"]                                  # models/cifar10/googlenet.py:171-184
 _BN_PARTS = [".weight", ".bias", ".running_mean", ".running_var"]
 
 
@@ -103,6 +131,105 @@ def vgg_16_bn_kept(compress_rate):
     widths = vgg_16_bn_widths(compress_rate)
     ori = [x for x in VGG_CFG if x != "M"]
     return [("imp_conv%d" % (k + 1), o, w) for k, (o, w) in enumerate(zip(ori, widths))]
+
+
+def _resnet_cifar_stage_out(num_layers):
+    rep = RESNET_CIFAR_REPEAT[num_layers]
+    return [16] + [16] * rep[0] + [32] * rep[1] + [64] * rep[2]
+
+
+def resnet_cifar_widths(compress_rate, num_layers):
+    """(overall_channel, mid_channel) of models/cifar10/resnet.py:5-30 for resnet_56 / resnet_110."""
+    rep = RESNET_CIFAR_REPEAT[num_layers]
+    rates = list(compress_rate)
+    stage_oup = [rates[0]]
+    for i in range(len(rep) - 1):
+        stage_oup += [rates[i + 1]] * rep[i]
+    stage_oup += [0.0] * rep[-1]
+    mid_rates = rates[len(rep):]
+    stage_out = _resnet_cifar_stage_out(num_layers)
+    overall = [int(c * (1 - r)) for c, r in zip(stage_out, stage_oup)]
+    mid = [int(stage_out[i] * (1 - mid_rates[i - 1])) for i in range(1, len(stage_out))]
+    return overall, mid
+
+
+def resnet_cifar_convs(num_layers):
+    """[(conv name, score file stem, block index, 'mid' | 'out')] in the order load_resnet_model visits
+    them (utils/load_models.py:83-94): score file cnt with cnt = 2, 3, ... (imp_conv1 is the stem's)."""
+    convs, cnt, blk = [], 1, 0
+    for layer, num in enumerate(RESNET_CIFAR_REPEAT[num_layers]):
+        for k in range(num):
+            for l in range(2):
+                cnt += 1
+                convs.append(("layer%d.%d.conv%d" % (layer + 1, k, l + 1), "imp_conv%d" % cnt, blk, "mid" if l == 0 else "out"))
+            blk += 1
+    return convs
+
+
+def resnet_cifar_kept(compress_rate, num_layers):
+    """[(score file stem, original width, kept width)] for the files the consumer reads."""
+    overall, mid = resnet_cifar_widths(compress_rate, num_layers)
+    stage_out = _resnet_cifar_stage_out(num_layers)
+    return [(stem, stage_out[blk + 1], mid[blk] if kind == "mid" else overall[blk + 1])
+            for _, stem, blk, kind in resnet_cifar_convs(num_layers)]
+
+
+def densenet_40_conv_names():
+    """The 39 convolutions in named_modules() order (models/cifar10/densenet.py:68-75)."""
+    names = ["conv1"]
+    for b in (1, 2, 3):
+        names += ["dense%d.%d.conv1" % (b, i) for i in range(DENSENET40_BLOCK)]
+        if b < 3:
+            names.append("trans%d.conv1" % b)
+    return names
+
+
+def densenet_40_widths(compress_rate):
+    """Output channels of the 39 convolutions (models/cifar10/densenet.py:67-75, :91-104): conv1 is never
+    pruned (compress_rate[0] is not read), a dense layer keeps int(12*(1-r)) filters, a transition
+    int(floor(inplanes*(1-r)))."""
+    n, rates = DENSENET40_BLOCK, list(compress_rate)
+    inplanes = 2 * DENSENET40_GROWTH
+    widths = [inplanes]
+    for b in range(3):
+        for r in rates[b * (n + 1) + 1:b * (n + 1) + 1 + n]:
+            w = int(DENSENET40_GROWTH * (1 - r))
+            widths.append(w)
+            inplanes += w
+        if b < 2:
+            inplanes = int(math.floor(inplanes * (1 - rates[(b + 1) * (n + 1)]) // 1))
+            widths.append(inplanes)
+    return widths
+
+
+def densenet_40_kept(compress_rate):
+    """[(score file stem, original width, kept width)], consumer order (cov_id = 1 ... 39)."""
+    ori = densenet_40_widths([0.0] * 39)
+    return [("imp_conv%d" % (k + 1), o, w) for k, (o, w) in enumerate(zip(ori, densenet_40_widths(compress_rate)))]
+
+
+def googlenet_widths(compress_rate, filters=None):
+    """Per Inception block (n1x1, 3x3 conv out, 5x5-branch middle conv out, 5x5-branch last conv out,
+    pool_planes) of the pruned net (models/cifar10/googlenet.py:28-66: int(n*(1-rate)), the last block
+    keeps the full width on its two branch outputs but not on the middle 5x5-branch conv)."""
+    filters = filters or GOOGLENET_FILTERS
+    out = []
+    for i, (n1, n3, n5, pool) in enumerate(filters):
+        keep = 1 - compress_rate[i + 1]
+        last = i == len(filters) - 1
+        out.append((n1, n3 if last else int(n3 * keep), int(n5 * keep), n5 if last else int(n5 * keep), pool))
+    return out
+
+
+def googlenet_kept(compress_rate, filters=None):
+    """[(score file stem, original width, kept width)] for the files the consumer reads (the _n5x5 file
+    of a block serves both 5x5-branch convs; listed once, with the middle conv's width)."""
+    filters = filters or GOOGLENET_FILTERS
+    out = []
+    for i, (w, f) in enumerate(zip(googlenet_widths(compress_rate, filters), filters)):
+        out.append(("imp_conv%d_n3x3" % (i + 2), f[1], w[1]))
+        out.append(("imp_conv%d_n5x5" % (i + 2), f[2], w[2]))
+    return out
 
 
 def _load_imp(imp_score, stem):
@@ -191,4 +318,119 @@ def transplant_resnet_50(state_dict, oristate_dict, imp_score):
     for key in ("fc.weight", "fc.bias"):
         if key in oristate_dict:
             state_dict[key] = oristate_dict[key]
+    return state_dict
+
+
+def transplant_resnet_cifar(state_dict, oristate_dict, imp_score, num_layers):
+    """utils/load_models.py:67-143 (load_resnet_model, layer = 56 or 110)."""
+    visited = set()
+    last = None
+    for conv, stem, _, _ in resnet_cifar_convs(num_layers):
+        key = conv + ".weight"
+        visited.add(key)
+        ori, cur = oristate_dict[key], state_dict[key]
+        o, c = ori.size(0), cur.size(0)
+        if o != c:
+            sel = select_index(_load_imp(imp_score, stem), o, c)
+            if last is not None:
+                cur[:, :len(last)] = _rows_cols(ori, sel, last)
+            else:
+                cur.copy_(_rows(ori, sel))
+            last = sel
+        elif last is not None:
+            cur[:, :len(last)] = _rows_cols(ori, None, last)
+            last = None  # :123 (the VGG loader keeps it here)
+        else:
+            state_dict[key] = ori
+            last = None
+    # :126-141: every other conv (the stem; shortcuts are parameter-free pads) and the linear layer whole
+    for key, t in oristate_dict.items():
+        if key.endswith(".weight") and t.dim() == 4 and key not in visited and "shortcut" not in key:
+            state_dict[key] = t
+        elif key.endswith(".weight") and t.dim() == 2:
+            state_dict[key] = t
+            state_dict[key[:-len("weight")] + "bias"] = oristate_dict[key[:-len("weight")] + "bias"]
+    return state_dict
+
+
+def transplant_densenet_40(state_dict, oristate_dict, imp_score, conv_names=None):
+    """utils/load_models.py:385-438 (load_densenet_model)."""
+    last = []  # :388 - a list from the start: the `last_select_index is not None` tests are always true
+    for cov_id, name in enumerate(conv_names or densenet_40_conv_names(), start=1):
+        key = name + ".weight"
+        ori, cur = oristate_dict[key], state_dict[key]
+        o, c = ori.size(0), cur.size(0)
+        if o != c:
+            sel = [int(i) for i in select_index(_load_imp(imp_score, "imp_conv%d" % cov_id), o, c)]
+            if last:
+                cur[:, :len(last)] = _rows_cols(ori, sel, last)
+        else:
+            if last:
+                cur[:, :len(last)] = _rows_cols(ori, None, last)
+            sel = list(range(o))
+        if cov_id in (1, 14, 27):  # :432 conv1 and the transitions restart the concatenation
+            last = list(sel)
+        else:
+            shift = cov_id * 12 - (cov_id - 1) // 13 * 12  # :435
+            last = last + [x + shift for x in sel]
+    return state_dict
+
+
+def transplant_googlenet(state_dict, oristate_dict, imp_score, filters=None, blocks=None):
+    """utils/load_models.py:146-382 (load_google_model with cpr=None, as load_model calls it). `filters`:
+    the original filter table the offsets come from (default: the reference's; tests pass a miniature)."""
+    filters = filters or GOOGLENET_FILTERS
+    blocks = blocks or GOOGLENET_BLOCKS
+    sketch_bn = {"pre_layers.1"}
+    cur_last = []
+    # pre_layers (cov_id 1, :332-358): transplanted only if it lost filters - the constructor never prunes it
+    ori, cur = oristate_dict["pre_layers.0.weight"], state_dict["pre_layers.0.weight"]
+    if ori.size(0) != cur.size(0):
+        sel = select_index(_load_imp(imp_score, "imp_conv1"), ori.size(0), cur.size(0))
+        cur_last = [int(i) for i in sel]
+        cur.copy_(_rows(ori, sel))
+    for b, name in enumerate(blocks):
+        cov_id, f = b + 2, filters[b]
+        sketch_bn |= {name + ".branch3x3.4", name + ".branch5x5.4", name + ".branch5x5.7"}
+        last, cur_last = cur_last, []
+        pool_part = []
+        for entry in (".branch1x1.0", ".branch3x3.0", ".branch5x5.0", ".branch_pool.1"):  # :208-242 input channels only
+            key = name + entry + ".weight"
+            ori, cur = oristate_dict[key], state_dict[key]
+            cols = last if ori.size(1) != cur.size(1) else None
+            n = len(cols) if cols is not None else ori.size(1)
+            if n:
+                cur[:, :n] = _rows_cols(ori[:cur.size(0)], None, cols)
+            if entry == ".branch1x1.0":
+                cur_last += list(range(cur.size(0)))
+            elif entry == ".branch_pool.1":
+                pool_part = [x + f[0] + f[1] + f[2] for x in range(cur.size(0))]
+        cur_last += pool_part  # appended before the 3x3 / 5x5 parts (:236-242 run before :275, :320)
+        sel5 = None
+        for entry, stem in ((".branch3x3.3", "_n3x3"), (".branch5x5.3", "_n5x5")):  # :244-279 filters only
+            key = name + entry + ".weight"
+            ori, cur = oristate_dict[key], state_dict[key]
+            o, c = ori.size(0), cur.size(0)
+            sel = [int(i) for i in select_index(_load_imp(imp_score, "imp_conv%d%s" % (cov_id, stem)), o, c)] if o != c else list(range(o))
+            cur[:len(sel)] = _rows(ori, sel)
+            if stem == "_n3x3":
+                cur_last += [x + f[0] for x in sel]
+            else:
+                sel5 = sel
+        key = name + ".branch5x5.6.weight"  # :281-328 filters and input channels
+        ori, cur = oristate_dict[key], state_dict[key]
+        cols = sel5 if ori.size(1) != cur.size(1) else list(range(ori.size(1)))
+        o, c = ori.size(0), cur.size(0)
+        sel = [int(i) for i in select_index(_load_imp(imp_score, "imp_conv%d_n5x5" % cov_id), o, c)] if o != c else list(range(o))
+        cur_last += [x + f[0] + f[1] for x in sel]
+        cur[:len(sel), :len(cols)] = _rows_cols(ori, sel, cols)
+    # :361-380: every conv is on the sketch list (nothing to copy, biases included); batch-norms off the
+    # list and the linear layer come over whole
+    for key in oristate_dict:
+        if key.endswith(".running_mean") and key[:-len(".running_mean")] not in sketch_bn:
+            for part in _BN_PARTS:
+                state_dict[key[:-len(".running_mean")] + part] = oristate_dict[key[:-len(".running_mean")] + part]
+        elif key.endswith(".weight") and oristate_dict[key].dim() == 2:
+            state_dict[key] = oristate_dict[key]
+            state_dict[key[:-len("weight")] + "bias"] = oristate_dict[key[:-len("weight")] + "bias"]
     return state_dict

@@ -2,8 +2,8 @@
 element as the reference writes them, for parity tests of dct_pruning_amd/transplant.py.
 Only tests/ may import this module.
 
-Restates utils/load_models.py:17-64 (load_vgg_model) and :441-582 (load_resnet_imagenet_model,
-resnet_50 branch). The reference iterates model.named_modules(); here the ordered list of conv
+Restates utils/load_models.py:17-64 (load_vgg_model), :67-143 (load_resnet_model), :385-438
+(load_densenet_model), :146-382 (load_google_model) and :441-582 (load_resnet_imagenet_model, resnet_50 branch). The reference iterates model.named_modules(); here the ordered list of conv
 module names is passed in (the state-dict keys are the same), and score files come from a dict
 {stem: array} instead of np.load(args.imp_score + '/imp_conv%d.npy'). Everything else - the branch
 structure, which tensors are copied scalar slice by scalar slice, which are rebound, when
@@ -11,6 +11,8 @@ last_select_index is kept or reset - follows the reference line by line.
 
 Pinned by: nothing in the reference (it has no tests); the restatement is checked by review against
 the cited lines. "parity unpinned" in the sense of the task statement."""
+import copy
+
 import numpy as np
 
 
@@ -148,4 +150,259 @@ def load_resnet_imagenet_model(state_dict, oristate_dict, imp):
     for key in ('fc.weight', 'fc.bias'):
         if key in oristate_dict:
             state_dict[key] = oristate_dict[key]
+    return state_dict
+
+
+def load_resnet_model(state_dict, oristate_dict, layer, imp, modules):
+    """utils/load_models.py:67-143. `modules`: [(name, 'conv' | 'linear')] - what the reference gets from
+    model.named_modules() filtered by isinstance(module, nn.Conv2d / nn.Linear) (:126-141)."""
+    cfg = {56: [9, 9, 9], 110: [18, 18, 18]}  # :68-71
+    current_cfg = cfg[layer]
+    last_select_index = None  # :76
+    all_conv_weight = []  # :78
+    cnt = 1  # :83
+    for layer, num in enumerate(current_cfg):  # :84
+        layer_name = 'layer' + str(layer + 1) + '.'
+        for k in range(num):  # :86
+            for l in range(2):  # :87
+                cnt += 1  # :89
+                cov_id = cnt
+                conv_name = layer_name + str(k) + '.conv' + str(l + 1)  # :92
+                conv_weight_name = conv_name + '.weight'
+                all_conv_weight.append(conv_weight_name)
+                oriweight = oristate_dict[conv_weight_name]
+                curweight = state_dict[conv_weight_name]
+                orifilter_num = oriweight.size(0)
+                currentfilter_num = curweight.size(0)
+                if orifilter_num != currentfilter_num:  # :100
+                    select_index = np.argsort(imp['imp_conv' + str(cov_id)])[orifilter_num - currentfilter_num:]  # :102-103
+                    select_index.sort()
+                    if last_select_index is not None:  # :106
+                        for index_i, i in enumerate(select_index):
+                            for index_j, j in enumerate(last_select_index):
+                                state_dict[conv_weight_name][index_i][index_j] = \
+                                    oristate_dict[conv_weight_name][i][j]
+                    else:  # :111
+                        for index_i, i in enumerate(select_index):
+                            state_dict[conv_weight_name][index_i] = \
+                                oristate_dict[conv_weight_name][i]
+                    last_select_index = select_index  # :116
+                elif last_select_index is not None:  # :118
+                    for index_i in range(orifilter_num):
+                        for index_j, j in enumerate(last_select_index):
+                            state_dict[conv_weight_name][index_i][index_j] = \
+                                oristate_dict[conv_weight_name][index_i][j]
+                    last_select_index = None  # :123
+                else:  # :125
+                    state_dict[conv_weight_name] = oriweight
+                    last_select_index = None
+    for name, kind in modules:  # :129
+        if kind == 'conv':
+            conv_name = name + '.weight'
+            if 'shortcut' in name:  # :134
+                continue
+            if conv_name not in all_conv_weight:
+                state_dict[conv_name] = oristate_dict[conv_name]
+        elif kind == 'linear':  # :139
+            state_dict[name + '.weight'] = oristate_dict[name + '.weight']
+            state_dict[name + '.bias'] = oristate_dict[name + '.bias']
+    return state_dict
+
+
+def load_densenet_model(state_dict, oristate_dict, imp, conv_names):
+    """utils/load_models.py:385-438."""
+    last_select_index = []  # :388 - an empty list, so every `is not None` below is true
+    cnt = 0
+    for name in conv_names:  # :393-396
+        cnt += 1
+        cov_id = cnt
+        oriweight = oristate_dict[name + '.weight']
+        curweight = state_dict[name + '.weight']
+        orifilter_num = oriweight.size(0)
+        currentfilter_num = curweight.size(0)
+        if orifilter_num != currentfilter_num:  # :405
+            select_index = list(np.argsort(imp['imp_conv' + str(cov_id)])[orifilter_num - currentfilter_num:])  # :407-408
+            select_index.sort()
+            if last_select_index is not None:  # :411
+                for index_i, i in enumerate(select_index):
+                    for index_j, j in enumerate(last_select_index):
+                        state_dict[name + '.weight'][index_i][index_j] = \
+                            oristate_dict[name + '.weight'][i][j]
+            else:
+                for index_i, i in enumerate(select_index):
+                    state_dict[name + '.weight'][index_i] = \
+                        oristate_dict[name + '.weight'][i]
+        elif last_select_index is not None:  # :421
+            for i in range(orifilter_num):
+                for index_j, j in enumerate(last_select_index):
+                    state_dict[name + '.weight'][i][index_j] = \
+                        oristate_dict[name + '.weight'][i][j]
+            select_index = list(range(0, orifilter_num))  # :426
+        else:
+            select_index = list(range(0, orifilter_num))  # :429
+            state_dict[name + '.weight'] = oriweight
+        if cov_id == 1 or cov_id == 14 or cov_id == 27:  # :432
+            last_select_index = select_index
+        else:
+            tmp_select_index = [x + cov_id * 12 - (cov_id - 1) // 13 * 12 for x in select_index]  # :435
+            last_select_index += tmp_select_index
+    return state_dict
+
+
+def load_google_model(state_dict, oristate_dict, imp, modules, filters=None):
+    """utils/load_models.py:146-382 with cpr=None (how load_model calls it, :822). `modules`: the
+    reference's model.named_modules() reduced to [(name, kind)] with kind in 'inception', 'pre_layers',
+    'conv', 'bn', 'linear', in module order. `filters`: the table of :149-159 (argument only so that
+    tests can run a miniature network; None = the reference's)."""
+    if filters is None:
+        filters = [
+            [64, 128, 32, 32],
+            [128, 192, 96, 64],
+            [192, 208, 48, 64],
+            [160, 224, 64, 64],
+            [128, 256, 64, 64],
+            [112, 288, 64, 64],
+            [256, 320, 128, 128],
+            [256, 320, 128, 128],
+            [384, 384, 128, 128]
+        ]
+    all_honey_conv_name = []  # :166
+    all_honey_bn_name = []
+    cur_last_select_index = []  # :168
+
+    def branch_of(weight_index):  # :211-218, :246-253, :283-290
+        if '3x3' in weight_index:
+            return '_n3x3'
+        elif '5x5' in weight_index:
+            return '_n5x5'
+        elif '1x1' in weight_index:
+            return '_n1x1'
+        elif 'pool' in weight_index:
+            return '_pool_planes'
+
+    cnt = 0  # :170
+    for name, kind in modules:  # :173
+        if kind == 'inception':  # :176
+            cnt += 1
+            cov_id = cnt
+            honey_filter_channel_index = ['.branch5x5.6']  # :181-183
+            honey_channel_index = ['.branch1x1.0', '.branch3x3.0', '.branch5x5.0', '.branch_pool.1']  # :184-189
+            honey_filter_index = ['.branch3x3.3', '.branch5x5.3']  # :190-193
+            honey_bn_index = ['.branch3x3.4', '.branch5x5.4', '.branch5x5.7']  # :194-198
+            for bn_index in honey_bn_index:
+                all_honey_bn_name.append(name + bn_index)
+            last_select_index = cur_last_select_index[:]  # :203
+            cur_last_select_index = []
+
+            for weight_index in honey_channel_index:  # :206
+                branch_name = branch_of(weight_index)
+                conv_name = name + weight_index + '.weight'
+                all_honey_conv_name.append(name + weight_index)
+                oriweight = oristate_dict[conv_name]
+                curweight = state_dict[conv_name]
+                orifilter_num = oriweight.size(1)  # :224 (input channels)
+                currentfilter_num = curweight.size(1)
+                if orifilter_num != currentfilter_num:
+                    select_index = last_select_index
+                else:
+                    select_index = list(range(0, orifilter_num))
+                for i in range(state_dict[conv_name].size(0)):  # :230
+                    for index_j, j in enumerate(select_index):
+                        state_dict[conv_name][i][index_j] = \
+                            oristate_dict[conv_name][i][j]
+                if branch_name == '_n1x1':  # :235
+                    tmp_select_index = list(range(state_dict[conv_name].size(0)))
+                    cur_last_select_index += tmp_select_index
+                if branch_name == '_pool_planes':  # :238
+                    tmp_select_index = list(range(state_dict[conv_name].size(0)))
+                    tmp_select_index = [x + filters[cov_id - 2][0] + filters[cov_id - 2][1] + filters[cov_id - 2][2]
+                                        for x in tmp_select_index]
+                    cur_last_select_index += tmp_select_index
+
+            for weight_index in honey_filter_index:  # :244
+                branch_name = branch_of(weight_index)
+                conv_name = name + weight_index + '.weight'
+                all_honey_conv_name.append(name + weight_index)
+                oriweight = oristate_dict[conv_name]
+                curweight = state_dict[conv_name]
+                orifilter_num = oriweight.size(0)
+                currentfilter_num = curweight.size(0)
+                if orifilter_num != currentfilter_num:  # :263
+                    select_index = np.argsort(imp['imp_conv' + str(cov_id) + branch_name])[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                else:
+                    select_index = list(range(0, orifilter_num))
+                for index_i, i in enumerate(select_index):  # :271
+                    state_dict[conv_name][index_i] = \
+                        oristate_dict[conv_name][i]
+                if branch_name == '_n3x3':  # :275
+                    tmp_select_index = [x + filters[cov_id - 2][0] for x in select_index]
+                    cur_last_select_index += tmp_select_index
+                if branch_name == '_n5x5':  # :278
+                    last_select_index = select_index
+
+            for weight_index in honey_filter_channel_index:  # :281
+                branch_name = branch_of(weight_index)
+                conv_name = name + weight_index + '.weight'
+                all_honey_conv_name.append(name + weight_index)
+                oriweight = oristate_dict[conv_name]
+                curweight = state_dict[conv_name]
+                orifilter_num = oriweight.size(1)  # :298
+                currentfilter_num = curweight.size(1)
+                if orifilter_num != currentfilter_num:
+                    select_index = last_select_index
+                else:
+                    select_index = range(0, orifilter_num)
+                orifilter_num = oriweight.size(0)  # :306
+                currentfilter_num = curweight.size(0)
+                select_index_1 = copy.deepcopy(select_index)  # :309
+                if orifilter_num != currentfilter_num:  # :311
+                    select_index = np.argsort(imp['imp_conv' + str(cov_id) + branch_name])[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                else:
+                    select_index = list(range(0, orifilter_num))
+                if branch_name == '_n5x5':  # :320
+                    tmp_select_index = [x + filters[cov_id - 2][0] + filters[cov_id - 2][1] for x in select_index]
+                    cur_last_select_index += tmp_select_index
+                for index_i, i in enumerate(select_index):  # :324
+                    for index_j, j in enumerate(select_index_1):
+                        state_dict[conv_name][index_i][index_j] = \
+                            oristate_dict[conv_name][i][j]
+
+        elif name == 'pre_layers':  # :329
+            cnt += 1
+            cov_id = cnt
+            honey_filter_index = ['.0']
+            honey_bn_index = ['.1']
+            for bn_index in honey_bn_index:
+                all_honey_bn_name.append(name + bn_index)
+            for weight_index in honey_filter_index:
+                conv_name = name + weight_index + '.weight'
+                all_honey_conv_name.append(name + weight_index)
+                oriweight = oristate_dict[conv_name]
+                curweight = state_dict[conv_name]
+                orifilter_num = oriweight.size(0)
+                currentfilter_num = curweight.size(0)
+                if orifilter_num != currentfilter_num:  # :350
+                    select_index = np.argsort(imp['imp_conv' + str(cov_id)])[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                    cur_last_select_index = select_index[:]
+                    for index_i, i in enumerate(select_index):
+                        state_dict[conv_name][index_i] = \
+                            oristate_dict[conv_name][i]
+
+    for name, kind in modules:  # :361 "Reassign non sketch weights to the new network"
+        if kind == 'conv':
+            if name not in all_honey_conv_name:
+                state_dict[name + '.weight'] = oristate_dict[name + '.weight']
+                state_dict[name + '.bias'] = oristate_dict[name + '.bias']
+        elif kind == 'bn':  # :369
+            if name not in all_honey_bn_name:
+                state_dict[name + '.weight'] = oristate_dict[name + '.weight']
+                state_dict[name + '.bias'] = oristate_dict[name + '.bias']
+                state_dict[name + '.running_mean'] = oristate_dict[name + '.running_mean']
+                state_dict[name + '.running_var'] = oristate_dict[name + '.running_var']
+        elif kind == 'linear':  # :377
+            state_dict[name + '.weight'] = oristate_dict[name + '.weight']
+            state_dict[name + '.bias'] = oristate_dict[name + '.bias']
     return state_dict
