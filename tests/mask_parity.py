@@ -35,11 +35,12 @@ from dct_pruning_amd.accumulate import HostAccumulator  # noqa: E402
 from dct_pruning_amd.data import load_data  # noqa: E402
 from oracle import dct_oracle as orc  # noqa: E402
 
-README_RATES = {  # /root/reference/README.md:90, :114, :138, :162, :211
+README_RATES = {  # /root/reference/README.md:90, :114, :138, :162, :186, :211
     "vgg_16_bn": [0.5] * 7 + [0.95] * 5,
     "resnet_56": [0.0] + [0.18] * 29,
     "resnet_110": [0.0] + [0.2] * 2 + [0.3] * 18 + [0.4] * 18 + [0.39] * 19,
     "densenet_40": [0.0] + [0.2] * 12 + [0.0] + [0.2] * 12 + [0.0] + [0.2] * 12,
+    "googlenet": [0.4] + [0.85] * 2 + [0.9] * 5 + [0.9] * 2,
     "resnet_50": [0.0] + [0.1] * 3 + [0.4] * 7 + [0.4] * 9,
 }
 GENERIC_RATES = (0.1, 0.3, 0.5, 0.7, 0.95)
@@ -53,6 +54,8 @@ def readme_kept(net):
         return {s: k for s, o, k in transplant.vgg_16_bn_kept(README_RATES[net]) if k != o}
     if net in ("resnet_56", "resnet_110"):
         return {s: k for s, o, k in transplant.resnet_cifar_kept(README_RATES[net], int(net.split("_")[1])) if k != o}
+    if net == "googlenet":
+        return {s: k for s, o, k in transplant.googlenet_kept(README_RATES[net]) if k != o}
     if net == "densenet_40":
         return {s: k for s, o, k in transplant.densenet_40_kept(README_RATES[net]) if k != o}
     return {}
