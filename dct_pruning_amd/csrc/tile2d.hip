@@ -128,20 +128,40 @@ template <int M>
 struct T2Cfg {
   static constexpr int L = kT2L, S = kT2S, N = M * S, NW = kT2Waves;
   static_assert(2 * M <= 64 && 2 * M > 32, "two blocks per wave");
-  static constexpr int RS = M | 1;   // block row stride: odd, conflict-free by column and by row
-  // floats per block, == 12 (mod 32) when M = 28 so that the second block's first lanes (28..31,
-  // same half-wave as the first block's 28 lanes) land on the four banks the first block leaves free
-  static constexpr int BS = M * RS;
+#ifndef DCTS_T2_XPOSE
+#define DCTS_T2_XPOSE 1
+#endif
+  // XP: a block is read by columns on BOTH axes (lane = column, consecutive words: conflict-free for any
+  // row stride) and transposed by axis A's WRITES: lane q' puts its outputs into row q' of the block,
+  // 16 bytes at a time (ds_write_b128; rows of M = 28 floats start 28 banks apart: eight lanes cover
+  // the 32 banks). ds_write_b32 costs 3-4 cycles per wave (tools/probes/valu_probe.hip), as much as a
+  // ds_read_b128, so this halves the LDS write time of the transforms. The second block / item row of a
+  // wave starts at lane 32: half-waves never share banks, row and block strides need no padding.
+  static constexpr bool XP = DCTS_T2_XPOSE != 0;
+  static constexpr int RS = XP ? M : (M | 1);   // block row stride (!XP: odd, conflict-free by column and by row)
+  // floats per block (!XP: == 12 (mod 32) when M = 28 so that the second block's first lanes (28..31,
+  // same half-wave as the first block's 28 lanes) land on the four banks the first block leaves free)
+  // (XP: + 4 pad words, where the lanes without an item put their unconditional stores)
+  static constexpr int BS = M * RS + (XP ? 4 : 0);
+  static constexpr int HW = XP ? 32 : M;      // first lane of the second block / item row
+  static_assert(!XP || (M % 4 == 0 && (M / 2) % 2 == 0 && M <= 32), "16-byte rows, even halves");
+  // position of axis A's output k in the transposed row: even k first, then odd k (the order the
+  // staged codelets finish them in, so every 16-byte group is complete when its stage ends)
+  static constexpr int pos_of_k(int k) { return XP ? ((k % 2 == 0) ? k / 2 : M / 2 + k / 2) : k; }
+  static constexpr int k_of_pos(int j) { return XP ? (j < M / 2 ? 2 * j : 2 * (j - M / 2) + 1) : j; }
   static constexpr int ZSET = (S * S / 2) * BS;       // floats: one set of 32 blocks
   static constexpr int PI = 64 / M;                   // item rows per producer wave (2)
   static constexpr int PWAVES = (M + PI - 1) / PI;    // producer waves (14 for M = 28)
   static_assert(PWAVES <= NW, "producers");
   static constexpr int NROT = 3;                      // rotations of the L = 3 network
+#ifndef DCTS_T2_PIN
+#define DCTS_T2_PIN 1
+#endif
 #ifndef DCTS_T2_DMACOLS
 #define DCTS_T2_DMACOLS 2
 #endif
 #ifndef DCTS_T2_HOOKS
-#define DCTS_T2_HOOKS 0, 0, 0, 12, 12, 12
+#define DCTS_T2_HOOKS 4, 4, 4, 12, 12, 12
 #endif
   // The last DB column slots of the NEXT map do not land in registers but in LDS (direct-to-LDS
   // loads into the 56 KB the Z set leaves free: no VGPRs, nothing for the register allocator to
@@ -245,6 +265,8 @@ __device__ unsigned long long g_t2_stamps[16][16];
 #define T2_STAMP(slot) ((void)0)
 #endif
 
+__device__ __forceinline__ void t2_pin(float& x) { asm volatile("" : "+v"(x)); }
+
 // the L = 3 role network on 8 values held in registers: y[slot], constants by lane
 template <int M>
 __device__ __forceinline__ void t2_network(float (&y)[kT2S], const float (&rc)[T2Cfg<M>::NROT][4]) {
@@ -261,6 +283,23 @@ __device__ __forceinline__ void t2_network(float (&y)[kT2S], const float (&rc)[T
       y[b] = yb * rc[r][2] - ya * rc[r][3];
     }
   });
+}
+
+// DCTS_T2_PRIO=2: every wave walks its issue priority through 0..3 at the stage boundaries of the leaf
+// codelets, the four waves of a SIMD (wave, wave + 4, ...) a step apart: at equal priority the arbiter
+// serves the oldest wave first and the four finish a phase one after the other (stamps: 5.0 / 6.1 / 7.9 /
+// 9.5 k cycles), the last one alone on its SIMD at a quarter of the issue rate.
+template <int K>
+__device__ __forceinline__ void t2_tick() {
+#if defined(DCTS_T2_PRIO) && DCTS_T2_PRIO == 2
+  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  switch ((g + K) & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+  }
+#endif
 }
 
 // Leaf transforms in stages, with scheduling barriers between the half-size sub-transforms and the
@@ -281,18 +320,21 @@ __device__ __forceinline__ void t2_dct2_staged(const float (&x)[M], Sink sink) {
     v[n] = x[n] - x[M - 1 - n];
   });
   __builtin_amdgcn_sched_barrier(0);
+  t2_tick<0>();
   {
     float E[H];
     dcts::Dct2<H>::run(u, E);
     dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE { sink(std::integral_constant<int, 2 * decltype(i)::value>{}, E[decltype(i)::value]); });
   }
   __builtin_amdgcn_sched_barrier(0);
+  t2_tick<1>();
   {
     float O[H];
     dcts::Dct4<H>::run(v, O);
     dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE { sink(std::integral_constant<int, 2 * decltype(i)::value + 1>{}, O[decltype(i)::value]); });
   }
   __builtin_amdgcn_sched_barrier(0);
+  t2_tick<2>();
 }
 template <int M, class Sink>
 __device__ __forceinline__ void t2_dct4_staged(const float (&v)[M], Sink sink) {
@@ -308,11 +350,14 @@ __device__ __forceinline__ void t2_dct4_staged(const float (&v)[M], Sink sink) {
     b[n] = v[M - 1 - n] * (sg * c) - v[n] * (sg * sn);
   });
   __builtin_amdgcn_sched_barrier(0);
+  t2_tick<0>();
   float A[H], B[H];
   dcts::Dct2<H>::run(a, A);
   __builtin_amdgcn_sched_barrier(0);
+  t2_tick<1>();
   dcts::Dct2<H>::run(b, B);
   __builtin_amdgcn_sched_barrier(0);
+  t2_tick<2>();
   sink(std::integral_constant<int, 0>{}, A[0]);
   sink(std::integral_constant<int, M - 1>{}, -B[0]);
   dcts::static_for<H - 1>([&](auto i) DCTS_LAMBDA_INLINE {
@@ -321,6 +366,99 @@ __device__ __forceinline__ void t2_dct4_staged(const float (&v)[M], Sink sink) {
     sink(std::integral_constant<int, 2 * jj - 1>{}, A[jj] - B[H - jj]);
   });
   __builtin_amdgcn_sched_barrier(0);
+  t2_tick<3>();
+}
+
+// The same staged codelets with the outputs handed over in two groups of M/2: even k after the first
+// stage, odd k after the second (DCT-II), or both at the end (DCT-IV), as arrays indexed by k / 2:
+// axis A stores a group as 16-byte pieces of the transposed row (T2Cfg::pos_of_k).
+template <int M, class Sink>
+__device__ __forceinline__ void t2_dct2_groups(const float (&x)[M], Sink sink) {
+  constexpr int H = M / 2;
+  float u[H], v[H];
+  dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int n = decltype(i)::value;
+    u[n] = x[n] + x[M - 1 - n];
+    v[n] = x[n] - x[M - 1 - n];
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<0>();
+  {
+    float E[H];
+    dcts::Dct2<H>::run(u, E);
+    sink(std::integral_constant<int, 0>{}, E);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<1>();
+  {
+    float O[H];
+    dcts::Dct4<H>::run(v, O);
+    sink(std::integral_constant<int, 1>{}, O);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<2>();
+}
+template <int M, class Sink>
+__device__ __forceinline__ void t2_dct4_groups(const float (&v)[M], Sink sink) {
+  constexpr int H = M / 2;
+  float a[H], b[H];
+  dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int n = decltype(i)::value;
+    constexpr float c = float(dcts::cospi_frac(2 * n + 1, 4 * M));
+    constexpr float sn = float(dcts::sinpi_frac(2 * n + 1, 4 * M));
+    constexpr float sg = (n % 2 == 0) ? 1.0f : -1.0f;
+    a[n] = v[n] * c + v[M - 1 - n] * sn;
+    b[n] = v[M - 1 - n] * (sg * c) - v[n] * (sg * sn);
+  });
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<0>();
+  float A[H], B[H];
+  dcts::Dct2<H>::run(a, A);
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<1>();
+  dcts::Dct2<H>::run(b, B);
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<2>();
+  {
+    float Ev[H];  // k = 0, 2, 4, ...
+    Ev[0] = A[0];
+    dcts::static_for<H - 1>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int jj = decltype(i)::value + 1;
+      Ev[jj] = A[jj] + B[H - jj];
+    });
+    sink(std::integral_constant<int, 0>{}, Ev);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<3>();
+  {
+    float Od[H];  // k = 1, 3, 5, ...
+    dcts::static_for<H - 1>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int jj = decltype(i)::value + 1;
+      Od[jj - 1] = A[jj] - B[H - jj];
+    });
+    Od[H - 1] = -B[0];
+    sink(std::integral_constant<int, 1>{}, Od);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  t2_tick<4>();
+}
+
+typedef float t2_v4f __attribute__((ext_vector_type(4)));
+typedef float t2_v2f __attribute__((ext_vector_type(2)));
+// H consecutive floats of an LDS row starting at word BASE (row 16-byte aligned): 16-byte stores
+// where BASE + i is a multiple of 4, 8-byte stores for the odd pair at either end
+template <int H, int BASE>
+__device__ __forceinline__ void t2_store_group(lds_ptr row, const float (&g)[H]) {
+  static_assert(H % 2 == 0 && BASE % 2 == 0, "pairs");
+  constexpr int lead = (BASE % 4 == 0) ? 0 : 2;
+  if constexpr (lead) *(__attribute__((address_space(3))) t2_v2f*)(row + BASE) = t2_v2f{g[0], g[1]};
+  constexpr int nq = (H - lead) / 4;
+  dcts::static_for<nq>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int o = lead + 4 * decltype(i)::value;
+    *(__attribute__((address_space(3))) t2_v4f*)(row + BASE + o) = t2_v4f{g[o], g[o + 1], g[o + 2], g[o + 3]};
+  });
+  constexpr int done = lead + 4 * nq;
+  if constexpr (done < H) *(__attribute__((address_space(3))) t2_v2f*)(row + BASE + done) = t2_v2f{g[done], g[done + 1]};
 }
 
 // One pass = two leaf blocks (lane halves). Each axis is straight-line code per codelet type, picked
@@ -336,30 +474,47 @@ struct T2Pass {
   int g, j, li;
   bool act;
   __device__ __forceinline__ T2Pass(lds_ptr zbuf, lds_cptr params, int set, int wave, int lane) {
-    g = lane >= M ? 1 : 0;
-    j = lane - g * M;
-    act = lane < 2 * M;
+    g = lane >= T2Cfg<M>::HW ? 1 : 0;
+    j = lane - g * T2Cfg<M>::HW;
+    act = j < M;
     li = 2 * wave + g;
     pp = params + (set * (kT2S * kT2S / 2) + li) * 8;
     blk = zbuf + li * T2Cfg<M>::BS;
   }
 };
 
-// axis A: lane = column q', transform along p', in place in the block's LDS image
+// axis A: lane = column q', transform along p'. !XP: in place in the block's LDS image. XP: the lane's
+// outputs go to ROW q' of the block (the transposition; every lane of the wave has read its column
+// before the first store is issued - the codelets consume all inputs in their first stage and a
+// wave's LDS operations complete in order), as 16-byte pieces in the order pos_of_k.
 template <int M, int TA>
 __device__ __forceinline__ void t2_axis_a(const T2Pass<M>& ps) {
-  constexpr int RS = T2Cfg<M>::RS;
+  using Cfg = T2Cfg<M>;
+  constexpr int RS = Cfg::RS;
   float in[M];
   lds_cptr src = ps.blk + (ps.act ? ps.j : 0);
   dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { in[decltype(i)::value] = src[decltype(i)::value * RS]; });
-  // this lane's own column. Unconditional stores (idle lanes hit the pad column M < RS, which nobody
-  // reads): an exec-masked store block kept all M outputs alive at once, 62 VGPRs instead of 44
-  lds_ptr dst = ps.blk + (ps.act ? ps.j : M);
-  auto put = [&](auto k, float val) DCTS_LAMBDA_INLINE { dst[decltype(k)::value * RS] = val; };
-  if constexpr (TA)
-    t2_dct4_staged<M>(in, put);
-  else
-    t2_dct2_staged<M>(in, put);
+  if constexpr (Cfg::XP) {
+    lds_ptr row = ps.blk + ps.j * RS;
+    const bool act = ps.act;
+    auto put = [&](auto half, const float (&g)[M / 2]) DCTS_LAMBDA_INLINE {
+      // exec-masked per group: the group's values are alive here anyway
+      if (act) t2_store_group<M / 2, decltype(half)::value * (M / 2)>(row, g);
+    };
+    if constexpr (TA)
+      t2_dct4_groups<M>(in, put);
+    else
+      t2_dct2_groups<M>(in, put);
+  } else {
+    // this lane's own column. Unconditional stores (idle lanes hit the pad column M < RS, which nobody
+    // reads): an exec-masked store block kept all M outputs alive at once, 62 VGPRs instead of 44
+    lds_ptr dst = ps.blk + (ps.act ? ps.j : M);
+    auto put = [&](auto k, float val) DCTS_LAMBDA_INLINE { dst[decltype(k)::value * RS] = val; };
+    if constexpr (TA)
+      t2_dct4_staged<M>(in, put);
+    else
+      t2_dct2_staged<M>(in, put);
+  }
 }
 
 // axis B: lane = row k1, transform along q'; returns the lane's weighted energy. A mixed pass (the
@@ -372,14 +527,15 @@ __device__ __forceinline__ float t2_axis_b(const T2Pass<M>& ps, int set, float* 
   auto run = [&](auto tb, bool mine) DCTS_LAMBDA_INLINE {
     constexpr int TB = decltype(tb)::value;
     float z[M];
-    lds_cptr src = ps.blk + (ps.act ? ps.j : 0) * RS;
-    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { z[decltype(i)::value] = src[decltype(i)::value]; });
+    // lane = row k1 of the half-transformed block. XP: that row is column j of the transposed image
+    lds_cptr src = ps.blk + (ps.act ? ps.j : 0) * (T2Cfg<M>::XP ? 1 : RS);
+    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { z[decltype(i)::value] = src[decltype(i)::value * (T2Cfg<M>::XP ? RS : 1)]; });
     float t0 = 0.f, t1 = 0.f;
     // debug / parity path: leaf outputs, unweighted, as [ra * M + k1][rb * M + k2] (k_assemble's layout)
     float* o = nullptr;
     if constexpr (STORE) {
       const int blk_id = __builtin_bit_cast(int, ps.pp[7]);
-      o = leaf_out + ((long long)((blk_id / kT2S) * M + ps.j) * (M * kT2S) + (blk_id % kT2S) * M);
+      o = leaf_out + ((long long)((blk_id / kT2S) * M + T2Cfg<M>::k_of_pos(ps.act ? ps.j : 0)) * (M * kT2S) + (blk_id % kT2S) * M);
     }
     auto sq = [&](auto k, float val) DCTS_LAMBDA_INLINE {
       if constexpr (decltype(k)::value == 0)
@@ -466,7 +622,7 @@ __device__ __forceinline__ float t2_axis_b_chain(int vid, const T2Pass<M>& ps, f
 // for the same pass) and everybody then waits for it at the barrier. Rotating a static priority
 // through the four of them at every hook point evens their progress out.
 __device__ __forceinline__ void t2_rotate_prio(int wave, int step) {
-#ifdef DCTS_T2_PRIO  // measured neutral (the phases are issue-bound: evening the waves out moves time from the barriers into the phases), off
+#if defined(DCTS_T2_PRIO) && DCTS_T2_PRIO == 1  // measured neutral (the phases are issue-bound: evening the waves out moves time from the barriers into the phases), off
   switch (((wave >> 2) + step) & 3) {
     case 0: __builtin_amdgcn_s_setprio(0); break;
     case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -591,10 +747,10 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
   float v[S][S];
   auto item_pq = [&](int& p, int& q, bool& ok) DCTS_LAMBDA_INLINE {
     const int lane = launder(lane_in);
-    const int pi = lane >= M ? 1 : 0;
-    q = lane - pi * M;
+    const int pi = lane >= Cfg::HW ? 1 : 0;
+    q = lane - pi * Cfg::HW;
     p = Cfg::PI * wave + pi;
-    ok = lane < Cfg::PI * M && p < M;
+    ok = q < M && pi < Cfg::PI && p < M;
     if (!ok) {
       p = 0;
       q = 0;
@@ -670,6 +826,11 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
       dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE {
         constexpr int a = decltype(ia)::value;
         t2_network<M>(v[a], rq);
+#if DCTS_T2_PIN
+        // the outputs exist HERE: LLVM otherwise sinks the networks down to the LDS stores of the set that
+        // uses them (behind the barrier, interleaved with the stores' address arithmetic: more live values)
+        dcts::static_for<S>([&](auto ib) DCTS_LAMBDA_INLINE { t2_pin(v[a][decltype(ib)::value]); });
+#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -683,9 +844,17 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
       bool ok;
       item_pq(p, q, ok);
       {
-        // lanes without an item store into the pad column (q' = M < RS), unconditionally: see t2_consume
+        // lanes without an item store unconditionally (see t2_consume) where nobody reads: the pad column
+        // (q' = M < RS), or with XP the four pad words behind the block
         const int qa = ok ? q : M, qd = ok ? M - 1 - q : M;
-        const int o_aa = p * RS + qa, o_ad = p * RS + qd, o_da = (M - 1 - p) * RS + qa, o_dd = (M - 1 - p) * RS + qd;
+        int o_aa = p * RS + qa, o_ad = p * RS + qd, o_da = (M - 1 - p) * RS + qa, o_dd = (M - 1 - p) * RS + qd;
+        if constexpr (Cfg::XP) {
+          const int dump = M * RS + (launder(lane_in) & 3);
+          o_aa = ok ? o_aa : dump;
+          o_ad = ok ? o_ad : dump;
+          o_da = ok ? o_da : dump;
+          o_dd = ok ? o_dd : dump;
+        }
         dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE {
           constexpr int ra = decltype(ia)::value;
           dcts::static_for<S>([&](auto ib) DCTS_LAMBDA_INLINE {
