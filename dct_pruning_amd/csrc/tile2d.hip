@@ -85,7 +85,13 @@ struct T2Sched {
       }
     for (int i = 0; i < NP; ++i) {
       const int set = i < NP / 2 ? 0 : 1;
-      const int w = set == 0 ? i : NP - 1 - i;  // wave
+#ifndef DCTS_T2_FLIP0
+#define DCTS_T2_FLIP0 0
+#endif
+      // wave. (DCTS_T2_FLIP0: the dearer passes of set 0 on the OLDER waves as well - at equal priority the
+      // arbiter serves the oldest wave of a SIMD first and wave w finishes a phase before wave w + 4
+      // whatever it runs; measured neutral, off.)
+      const int w = set == 0 ? (DCTS_T2_FLIP0 ? NP / 2 - 1 - i : i) : NP - 1 - i;
       for (int g = 0; g < 2; ++g) {
         const int b = pairs[i][g];
         blk[set][2 * w + g] = b;

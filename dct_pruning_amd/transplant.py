@@ -434,3 +434,143 @@ def transplant_googlenet(state_dict, oristate_dict, imp_score, filters=None, blo
             state_dict[key] = oristate_dict[key]
             state_dict[key[:-len("weight")] + "bias"] = oristate_dict[key[:-len("weight")] + "bias"]
     return state_dict
+
+
+# ---------------------------------------------------------------------------------------------
+# U^2-Net-p (models/DUTS/u2net.py, utils/load_models.py:585-769)
+# ---------------------------------------------------------------------------------------------
+U2NETP_DEPTH = {1: 7, 2: 6, 3: 5, 4: 4, 5: 4, 6: 4}   # RSU7, RSU6, RSU5, RSU4, RSU4F, RSU4F (models/DUTS/u2net.py:455-477)
+
+
+def u2netp_conv_shapes(compress_rate, in_ch=3, out_ch=1, inner=16, outer=64):
+    """[(conv module name, out channels, in channels)] of U2NETP(compress_rate) in named_modules() order,
+    'outconv' excluded (models/DUTS/u2net.py:34-79, :137-175, :219-251, :288-313, :344-365, :386-486).
+    Inside an RSU of depth D the first D-2 inner widths follow the rates (at least 1 channel), the two
+    deepest convs keep `inner`; the five outer widths follow compress_rate[34:39]. `inner` / `outer`
+    are 16 / 64 in the reference (smaller values give the tests a cheap network of the same shape)."""
+    r = list(compress_rate)
+    spans = {(1, False): (0, 5), (2, False): (5, 9), (3, False): (9, 12), (4, False): (12, 14), (5, False): (14, 16),
+             (6, False): (16, 18), (1, True): (18, 23), (2, True): (23, 27), (3, True): (27, 30), (4, True): (30, 32),
+             (5, True): (32, 34)}                                                     # adapt_channel, :386-401
+    ext = [max(1, int((1 - x) * outer)) for x in r[34:39]]                           # :438-452
+    m1, m2, m3, m4, m5 = ext
+
+    def rsu(prefix, stage, rates, cin, cout):
+        depth = U2NETP_DEPTH[stage]
+        mid = [max(1, int((1 - rates[k]) * inner)) for k in range(depth - 2)] + [inner]  # mid_ch1 .. mid_ch{D-1}
+        convs = [(prefix + ".rebnconvin.conv_s1", cout, cin), (prefix + ".rebnconv1.conv_s1", mid[0], cout)]
+        for k in range(2, depth):
+            convs.append((prefix + ".rebnconv%d.conv_s1" % k, mid[k - 1], mid[k - 2]))
+        convs.append((prefix + ".rebnconv%d.conv_s1" % depth, mid[depth - 2], mid[depth - 2]))
+        for k in range(depth - 1, 1, -1):
+            convs.append((prefix + ".rebnconv%dd.conv_s1" % k, mid[k - 2], 2 * mid[k - 1]))
+        convs.append((prefix + ".rebnconv1d.conv_s1", cout, 2 * mid[0]))
+        return convs
+
+    enc = [(1, in_ch, m1), (2, m1, m2), (3, m2, m3), (4, m3, m4), (5, m4, m5), (6, m5, m5)]
+    dec = [(5, 2 * m5, m4), (4, 2 * m4, m3), (3, 2 * m3, m2), (2, 2 * m2, m1), (1, 2 * m1, m1)]
+    out = []
+    for stage, cin, cout in enc:
+        lo, hi = spans[(stage, False)]
+        out += rsu("stage%d" % stage, stage, r[lo:hi], cin, cout)
+    for stage, cin, cout in dec:
+        lo, hi = spans[(stage, True)]
+        out += rsu("stage%dd" % stage, stage, r[lo:hi], cin, cout)
+    for k, c in zip(range(1, 7), (m1, m1, m2, m3, m4, m5)):                          # :479-484
+        out.append(("side%d" % k, out_ch, c))
+    return out
+
+
+def transplant_u2netp(state_dict, oristate_dict, imp_score, conv_names=None):
+    """utils/load_models.py:585-769 (load_u2netp_model), the copy loops as index_select. Only conv
+    `.weight` tensors are written (no conv bias, no batch-norm tensor, :609-610); the control flow -
+    stage counter, the three lists of remembered indices, which branches read a score file - is the
+    reference's, including where it raises (an un-pruned decoder `rebnconvin` behind a pruned layer
+    evaluates int('i'), :658; a stage that starts with no live index evaluates list(None), :617/:621)."""
+    if conv_names is None:
+        conv_names = [n for n, _, _ in u2netp_conv_shapes([0.0] * 39)]
+    last = None
+    cnt, stage_id = 0, 1
+    saved, saved_stage, saved_side = [], [], []
+
+    def cols(dst, src_rows, col_idx, col_base, dst0):
+        """dst[:, dst0 + k] = src_rows[:, col_idx[k] + col_base]"""
+        idx = torch.as_tensor(np.asarray(col_idx, dtype=np.int64) + col_base, dtype=torch.long, device=src_rows.device)
+        dst[:, dst0:dst0 + len(col_idx)] = src_rows.index_select(1, idx).to(dst.dtype)
+
+    for name in conv_names:
+        if name == "outconv":
+            break
+        side_name = name.split(".")[0]
+        is_side = side_name[:4] == "side"
+        decode = side_name[-1] == "d"
+        flag = "d." if decode else "."
+        midfix = None if is_side else name.split(".")[1]
+        key = name + ".weight"
+        ori, cur = oristate_dict[key], state_dict[key]
+        o, c, oin = ori.size(0), cur.size(0), ori.size(1)
+        cov_id = None if is_side else midfix[-2:]
+        if decode and side_name[-2] != str(stage_id):                                   # :616-619
+            stage_id -= 1
+            saved_side.append(list(last))
+            saved = []
+        elif (not decode) and side_name[-1] != str(stage_id):                           # :620-623
+            stage_id += 1
+            saved_stage.append(list(last))
+            saved = []
+
+        def rank():
+            return _load_imp(imp_score, "net.stage%d%s%s.relu_s1" % (stage_id, flag, midfix))
+
+        if not is_side:
+            if decode and cov_id == "in":
+                second = "stage"          # second half of the input: the encoder stage's output (:638)
+            elif cov_id[1] != "d":
+                second = None
+            else:
+                second = "unit"           # the RSU's own rebnconv<k> (:717)
+            if o != c:
+                sel = select_index(rank(), o, c)
+                rows = _rows(ori, sel)
+                if second is None:
+                    if last is not None:
+                        cols(cur, rows, last, 0, 0)
+                    else:
+                        cur.copy_(rows)
+                else:
+                    other = saved_stage[stage_id - 1] if second == "stage" else saved[int(cov_id[0])]
+                    cols(cur, rows, last, 0, 0)
+                    cols(cur, rows, other, int(oin / 2), len(last))
+                last = sel
+                if second != "unit":
+                    saved.append(list(sel))
+            elif last is not None:
+                sel = select_index(rank(), o, c)
+                if second is not None:
+                    other = saved[int(cov_id[0])]  # :658 reads cov_id[0] for 'in' too (ValueError there)
+                cols(cur, ori, last, 0, 0)
+                if second is not None:
+                    cols(cur, ori, other, int(oin / 2), len(last))
+                last = sel
+                if second != "unit":
+                    saved.append(list(sel))
+            else:
+                state_dict[key] = ori
+                last = None
+                if second != "unit":
+                    saved.append(None)
+        else:
+            cnt += 1
+            if o != c:
+                sel = select_index(_load_imp(imp_score, "net.side%d" % cnt), o, c)
+                rows = _rows(ori, sel)
+                if last is not None:
+                    cols(cur, rows, last, 0, 0)
+                else:
+                    cur.copy_(rows)
+            elif last is not None:
+                cols(cur, ori, last, 0, 0)
+            else:
+                state_dict[key] = ori
+            last = saved_side[5 - cnt]                                                   # :767
+    return state_dict

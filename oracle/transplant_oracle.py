@@ -3,14 +3,19 @@ element as the reference writes them, for parity tests of dct_pruning_amd/transp
 Only tests/ may import this module.
 
 Restates utils/load_models.py:17-64 (load_vgg_model), :67-143 (load_resnet_model), :385-438
-(load_densenet_model), :146-382 (load_google_model) and :441-582 (load_resnet_imagenet_model, resnet_50 branch). The reference iterates model.named_modules(); here the ordered list of conv
+(load_densenet_model), :146-382 (load_google_model), :441-582 (load_resnet_imagenet_model, resnet_50 branch) and :585-769 (load_u2netp_model). The reference iterates model.named_modules(); here the ordered list of conv
 module names is passed in (the state-dict keys are the same), and score files come from a dict
 {stem: array} instead of np.load(args.imp_score + '/imp_conv%d.npy'). Everything else - the branch
 structure, which tensors are copied scalar slice by scalar slice, which are rebound, when
 last_select_index is kept or reset - follows the reference line by line.
 
-Pinned by: nothing in the reference (it has no tests); the restatement is checked by review against
-the cited lines. "parity unpinned" in the sense of the task statement."""
+Pinned by: tests/golden/transplant_<net>.json - digests of the state dicts the REFERENCE's own loaders
+produce at full width on seeded weights and score files (tests/golden/make_transplant_goldens.py ran
+utils/load_models.py in the build container). tests/test_transplant_goldens.py holds the restatements of
+load_vgg_model, load_densenet_model, load_resnet_model (56) and load_u2netp_model to those digests; the
+ResNet-50 and GoogLeNet restatements run for a minute at full width and are tied to the pinned ones only
+through dct_pruning_amd/transplant.py (equal to them on miniature networks, equal to the reference's
+digests at full width)."""
 import copy
 
 import numpy as np
@@ -405,4 +410,159 @@ def load_google_model(state_dict, oristate_dict, imp, modules, filters=None):
         elif kind == 'linear':  # :377
             state_dict[name + '.weight'] = oristate_dict[name + '.weight']
             state_dict[name + '.bias'] = oristate_dict[name + '.bias']
+    return state_dict
+
+
+def load_u2netp_model(state_dict, oristate_dict, imp, conv_names):
+    """utils/load_models.py:585-769. `conv_names`: the Conv2d modules in named_modules() order (the
+    loop breaks at 'outconv', :598-599); `imp`: {file stem without '.npy': array} for
+    args.imp_score + '/net.stage<k>[d].<unit>.relu_s1.npy' and '/net.side<k>.npy'. The reference's
+    own failure modes are kept: `list(None)` when a stage starts while no index is live (:617, :621),
+    `int('i')` for an un-pruned decoder rebnconvin behind a pruned layer (:658) and indexing a None
+    entry of save_select_index raise here exactly as they do there."""
+    last_select_index = None  # :587
+    cnt = 0  # :589
+    stage_id = 1  # :590
+    save_select_index = []  # :591
+    save_stage_select_index = []  # :592
+    save_side_select_index = []  # :593
+
+    def rank_of(stage_id, flag, midfix):  # :629-630 and its repeats
+        return imp['net.stage' + str(stage_id) + flag + midfix + '.relu_s1']
+
+    for name in conv_names:  # :595-601
+        if name == 'outconv':
+            break
+        side_name = name.split('.')[0]  # :602
+        decode = True if side_name[-1] == 'd' else False  # :603
+        flag = '.' if not decode else 'd.'  # :604
+        midfix = name.split('.')[1] if not side_name[:4] == 'side' else None  # :607
+        oriweight = oristate_dict[name + '.weight']  # :609
+        curweight = state_dict[name + '.weight']  # :610
+        orifilter_num = oriweight.size(0)  # :611
+        currentfilter_num = curweight.size(0)  # :612
+        oriin_num = oriweight.size(1)  # :613
+        cov_id = midfix[-2:] if not side_name[:4] == 'side' else None  # :615
+        if decode == True and side_name[-2] != str(stage_id):  # :616
+            stage_id -= 1
+            save_side_select_index.append(list(last_select_index))
+            save_select_index = []
+        elif decode == False and side_name[-1] != str(stage_id):  # :620
+            stage_id += 1
+            save_stage_select_index.append(list(last_select_index))
+            save_select_index = []
+
+        if midfix != None:  # :625
+            if decode == True and cov_id == 'in':  # :627
+                if orifilter_num != currentfilter_num:  # :628
+                    rank = rank_of(stage_id, flag, midfix)
+                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                    for index_i, i in enumerate(select_index):  # :634-640
+                        for index_j, j in enumerate(last_select_index):
+                            state_dict[name + '.weight'][index_i][index_j] = \
+                                oristate_dict[name + '.weight'][i][j]
+                        for index_k, k in enumerate(save_stage_select_index[stage_id - 1]):
+                            state_dict[name + '.weight'][index_i][index_k + len(last_select_index)] = \
+                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
+                    last_select_index = select_index  # :642
+                    save_select_index.append(list(select_index))
+                elif last_select_index is not None:  # :645
+                    rank = rank_of(stage_id, flag, midfix)
+                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                    for i in range(orifilter_num):  # :651-657
+                        for index_j, j in enumerate(last_select_index):
+                            state_dict[name + '.weight'][i][index_j] = \
+                                oristate_dict[name + '.weight'][i][j]
+                        for index_k, k in enumerate(save_select_index[int(cov_id[0])]):
+                            state_dict[name + '.weight'][i][index_k + len(last_select_index)] = \
+                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
+                    last_select_index = select_index
+                    save_select_index.append(list(select_index))
+                else:  # :662
+                    state_dict[name + '.weight'] = oriweight
+                    last_select_index = None
+                    save_select_index.append(None)
+            elif cov_id[1] != 'd':  # :667
+                if orifilter_num != currentfilter_num:
+                    rank = rank_of(stage_id, flag, midfix)
+                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                    if last_select_index is not None:  # :674
+                        for index_i, i in enumerate(select_index):
+                            for index_j, j in enumerate(last_select_index):
+                                state_dict[name + '.weight'][index_i][index_j] = \
+                                    oristate_dict[name + '.weight'][i][j]
+                    else:  # :679
+                        for index_i, i in enumerate(select_index):
+                            state_dict[name + '.weight'][index_i] = \
+                                oristate_dict[name + '.weight'][i]
+                    last_select_index = select_index
+                    save_select_index.append(list(select_index))
+                elif last_select_index is not None:  # :687
+                    rank = rank_of(stage_id, flag, midfix)
+                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                    for i in range(orifilter_num):
+                        for index_j, j in enumerate(last_select_index):
+                            state_dict[name + '.weight'][i][index_j] = \
+                                oristate_dict[name + '.weight'][i][j]
+                    last_select_index = select_index
+                    save_select_index.append(list(select_index))
+                else:  # :701
+                    state_dict[name + '.weight'] = oriweight
+                    last_select_index = None
+                    save_select_index.append(None)
+            else:  # :706  rebnconv<k>d
+                if orifilter_num != currentfilter_num:
+                    rank = rank_of(stage_id, flag, midfix)
+                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                    for index_i, i in enumerate(select_index):  # :713-719
+                        for index_j, j in enumerate(last_select_index):
+                            state_dict[name + '.weight'][index_i][index_j] = \
+                                oristate_dict[name + '.weight'][i][j]
+                        for index_k, k in enumerate(save_select_index[int(cov_id[0])]):
+                            state_dict[name + '.weight'][index_i][index_k + len(last_select_index)] = \
+                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
+                    last_select_index = select_index
+                elif last_select_index is not None:  # :723
+                    rank = rank_of(stage_id, flag, midfix)
+                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
+                    select_index.sort()
+                    for i in range(orifilter_num):
+                        for index_j, j in enumerate(last_select_index):
+                            state_dict[name + '.weight'][i][index_j] = \
+                                oristate_dict[name + '.weight'][i][j]
+                        for index_k, k in enumerate(save_select_index[int(cov_id[0])]):
+                            state_dict[name + '.weight'][i][index_k + len(last_select_index)] = \
+                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
+                    last_select_index = select_index
+                else:  # :738
+                    state_dict[name + '.weight'] = oriweight
+                    last_select_index = None
+        else:  # :742  side<k>
+            cnt += 1
+            if orifilter_num != currentfilter_num:
+                rank = imp['net.side%d' % cnt]
+                select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
+                select_index.sort()
+                if last_select_index is not None:
+                    for index_i, i in enumerate(select_index):
+                        for index_j, j in enumerate(last_select_index):
+                            state_dict[name + '.weight'][index_i][index_j] = \
+                                oristate_dict[name + '.weight'][i][j]
+                else:
+                    for index_i, i in enumerate(select_index):
+                        state_dict[name + '.weight'][index_i] = \
+                            oristate_dict[name + '.weight'][i]
+            elif last_select_index is not None:  # :758
+                for i in range(orifilter_num):
+                    for index_j, j in enumerate(last_select_index):
+                        state_dict[name + '.weight'][i][index_j] = \
+                            oristate_dict[name + '.weight'][i][j]
+            else:  # :764
+                state_dict[name + '.weight'] = oriweight
+            last_select_index = save_side_select_index[5 - cnt]  # :767
     return state_dict

@@ -285,3 +285,83 @@ def test_googlenet_transplant_equals_reference_loops(device, rates):
     got = tp.transplant_googlenet({k: v.clone().to(device) for k, v in slim.items()},
                                   {k: v.clone().to(device) for k, v in ori.items()}, imp, MINI_FILTERS)
     assert_same(got, want)
+
+
+# ---- U^2-Net-p (utils/load_models.py:585-769) -------------------------------------------------------
+U2_RATES = [0.40] * 40                                                  # prune_u2netp.py:99 (the default)
+U2_MIXED = ([0.4, 0.0, 0.5, 0.0, 0.25] + [0.5, 0.0, 0.0, 0.4] + [0.0, 0.3, 0.3] + [0.5, 0.0] + [0.0, 0.0] + [0.25, 0.5]
+            + [0.0] * 5 + [0.3, 0.3, 0.0, 0.6] + [0.5] * 3 + [0.0, 0.4] + [0.9, 0.1] + [0.3, 0.5, 0.2, 0.4, 0.6])
+
+
+def mini_u2netp(g, rates, inner=8, outer=16):
+    """conv weights of U2NETP(compress_rate) at reduced base widths + a bias and batch-norm tensors per
+    unit, which the loader must leave alone (utils/load_models.py:609-610 touch '.weight' only)."""
+    sd, names = {}, []
+    for name, cout, cin in tp.u2netp_conv_shapes(rates, inner=inner, outer=outer):
+        sd[name + ".weight"] = _rand(g, cout, cin, 3, 3)
+        sd[name + ".bias"] = _rand(g, cout)
+        if name.endswith("conv_s1"):
+            bn = name[:-len("conv_s1")] + "bn_s1"
+            for part in (".weight", ".bias", ".running_mean", ".running_var"):
+                sd[bn + part] = _rand(g, cout)
+        names.append(name)
+    sd["outconv.weight"] = _rand(g, 1, 6, 1, 1)
+    return sd, names + ["outconv"]
+
+
+def u2_scores(g, ori, names):
+    stems = []
+    for n in names:
+        if n == "outconv":
+            continue
+        parts = n.split(".")
+        stems.append(("net." + n if len(parts) == 1 else "net.%s.%s.relu_s1" % (parts[0], parts[1]), n))
+    return scores_for(g, ori, stems)
+
+
+def test_u2netp_width_table_follows_the_reference_constructor():
+    full = tp.u2netp_conv_shapes([0.0] * 39)
+    assert len(full) == 118 and full[0] == ("stage1.rebnconvin.conv_s1", 64, 3)
+    assert full[7] == ("stage1.rebnconv7.conv_s1", 16, 16) and full[8] == ("stage1.rebnconv6d.conv_s1", 16, 32)
+    assert full[13] == ("stage1.rebnconv1d.conv_s1", 64, 32) and full[-1] == ("side6", 1, 64)
+    slim = dict((n, (o, i)) for n, o, i in tp.u2netp_conv_shapes(U2_RATES))
+    # models/DUTS/u2net.py:37-42: int(0.6 * 16) = 9 inside, the two deepest convs keep 16; :438-442: int(0.6 * 64) = 38
+    assert slim["stage1.rebnconv1.conv_s1"] == (9, 38) and slim["stage1.rebnconv6.conv_s1"] == (16, 9)
+    assert slim["stage1.rebnconv7.conv_s1"] == (16, 16) and slim["stage1.rebnconv6d.conv_s1"] == (9, 32)
+    assert slim["stage5d.rebnconvin.conv_s1"] == (38, 76) and slim["stage6.rebnconv1d.conv_s1"] == (38, 18)
+    assert slim["side3"] == (1, 38)
+    # a rate of 1.0 leaves one channel (:43-52)
+    assert dict((n, o) for n, o, _ in tp.u2netp_conv_shapes([1.0] * 39))["stage2.rebnconv1.conv_s1"] == 1
+    # the module names are those of the network this repo hooks
+    from dct_pruning_amd import nets
+    convs = [n for n, m in nets.U2NETP().named_modules() if isinstance(m, torch.nn.Conv2d)]
+    assert convs == [n for n, _, _ in full] + ["outconv"]
+
+
+@pytest.mark.parametrize("rates", [U2_RATES, U2_MIXED])
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_u2netp_transplant_equals_reference_loops(device, rates):
+    g = torch.Generator().manual_seed(17)
+    ori, names = mini_u2netp(g, [0.0] * 39)
+    slim, _ = mini_u2netp(g, rates)
+    imp = u2_scores(g, ori, names)
+    want = orc_t.load_u2netp_model(copy.deepcopy(slim), copy.deepcopy(ori), imp, names)
+    got = tp.transplant_u2netp({k: v.clone().to(device) for k, v in slim.items()},
+                               {k: v.clone().to(device) for k, v in ori.items()}, imp, names)
+    assert_same(got, want)
+    # something was pruned and transplanted, and nothing but conv weights moved
+    assert any(got[k].shape != ori[k].shape for k in got)
+    assert all(torch.equal(got[k].cpu(), slim[k]) for k in got if not k.endswith("conv_s1.weight") and "side" not in k)
+
+
+@pytest.mark.parametrize("rates,exc", [([0.0] * 39, TypeError),                                   # list(None), :621
+                                       ([0.4] * 34 + [0.4, 0.4, 0.4, 0.0, 0.4], ValueError)])      # int('i'), :658
+def test_u2netp_transplant_fails_where_the_reference_fails(rates, exc):
+    g = torch.Generator().manual_seed(18)
+    ori, names = mini_u2netp(g, [0.0] * 39)
+    slim, _ = mini_u2netp(g, rates)
+    imp = u2_scores(g, ori, names)
+    with pytest.raises(exc):
+        orc_t.load_u2netp_model(copy.deepcopy(slim), copy.deepcopy(ori), imp, names)
+    with pytest.raises(exc):
+        tp.transplant_u2netp(copy.deepcopy(slim), copy.deepcopy(ori), imp, names)
