@@ -20,9 +20,9 @@
 // a leaf is a 2-D transform, DCT-II or DCT-IV of length M per axis, RoleLeaf<>::is4). The transforms
 // commute: (C_leaf o B_col) X (B_row^T o C_leaf^T) = C_leaf (B_col X B_row^T) C_leaf^T.
 // A leaf block is then transformed by one wave exactly like a small tile in k_energy_codelet:
-// lane = column, M-point codelet, transposed IN PLACE in the block's own LDS image (every lane
-// overwrites only the column it read), lane = row, second codelet, squares.
-// LDS traffic: 2 writes + 2 reads per point; workgroup barriers: 4 per map.
+// lane = column, M-point codelet, transposed IN PLACE in the block's own LDS image (the wave that owns
+// the block reads it by columns and writes 16-byte pieces of rows: T2Cfg), lane = row, second codelet,
+// squares. LDS traffic: 2 writes + 2 reads per point; workgroup barriers: 4 per map.
 //
 // One workgroup of 16 waves per CU, persistent over maps. The 64 blocks of a map go through LDS in
 // two sets of 32 (a 224 x 224 tile is 196 KiB, the LDS 160 KiB): an item's 32 outputs of the second
@@ -85,13 +85,8 @@ struct T2Sched {
       }
     for (int i = 0; i < NP; ++i) {
       const int set = i < NP / 2 ? 0 : 1;
-#ifndef DCTS_T2_FLIP0
-#define DCTS_T2_FLIP0 0
-#endif
-      // wave. (DCTS_T2_FLIP0: the dearer passes of set 0 on the OLDER waves as well - at equal priority the
-      // arbiter serves the oldest wave of a SIMD first and wave w finishes a phase before wave w + 4
-      // whatever it runs; measured neutral, off.)
-      const int w = set == 0 ? (DCTS_T2_FLIP0 ? NP / 2 - 1 - i : i) : NP - 1 - i;
+      // wave (putting set 0's dearer passes on the older waves as well measured neutral)
+      const int w = set == 0 ? i : NP - 1 - i;
       for (int g = 0; g < 2; ++g) {
         const int b = pairs[i][g];
         blk[set][2 * w + g] = b;
@@ -134,35 +129,26 @@ template <int M>
 struct T2Cfg {
   static constexpr int L = kT2L, S = kT2S, N = M * S, NW = kT2Waves;
   static_assert(2 * M <= 64 && 2 * M > 32, "two blocks per wave");
-#ifndef DCTS_T2_XPOSE
-#define DCTS_T2_XPOSE 1
-#endif
-  // XP: a block is read by columns on BOTH axes (lane = column, consecutive words: conflict-free for any
-  // row stride) and transposed by axis A's WRITES: lane q' puts its outputs into row q' of the block,
-  // 16 bytes at a time (ds_write_b128; rows of M = 28 floats start 28 banks apart: eight lanes cover
-  // the 32 banks). ds_write_b32 costs 3-4 cycles per wave (tools/probes/valu_probe.hip), as much as a
+  // A block is read by columns on BOTH axes (lane = column, consecutive words: conflict-free for any row
+  // stride) and transposed by axis A's WRITES: lane q' puts its outputs into row q' of the block, 16
+  // bytes at a time (ds_write_b128; rows of M = 28 floats start 28 banks apart: eight lanes cover the 32
+  // banks). ds_write_b32 costs 3-4 cycles per wave (tools/probes/valu_probe.hip), as much as a
   // ds_read_b128, so this halves the LDS write time of the transforms. The second block / item row of a
   // wave starts at lane 32: half-waves never share banks, row and block strides need no padding.
-  static constexpr bool XP = DCTS_T2_XPOSE != 0;
-  static constexpr int RS = XP ? M : (M | 1);   // block row stride (!XP: odd, conflict-free by column and by row)
-  // floats per block (!XP: == 12 (mod 32) when M = 28 so that the second block's first lanes (28..31,
-  // same half-wave as the first block's 28 lanes) land on the four banks the first block leaves free)
-  // (XP: + 4 pad words, where the lanes without an item put their unconditional stores)
-  static constexpr int BS = M * RS + (XP ? 4 : 0);
-  static constexpr int HW = XP ? 32 : M;      // first lane of the second block / item row
-  static_assert(!XP || (M % 4 == 0 && (M / 2) % 2 == 0 && M <= 32), "16-byte rows, even halves");
+  // (Before: in-place column writes, odd row stride 29, the second block at lane 28.)
+  static constexpr int RS = M;                // block row stride
+  static constexpr int BS = M * RS + 4;       // floats per block; 4 pad words take the unconditional stores of lanes without an item
+  static constexpr int HW = 32;               // first lane of the second block / item row
+  static_assert(M % 4 == 0 && (M / 2) % 2 == 0 && M <= 32, "16-byte rows, even halves");
   // position of axis A's output k in the transposed row: even k first, then odd k (the order the
   // staged codelets finish them in, so every 16-byte group is complete when its stage ends)
-  static constexpr int pos_of_k(int k) { return XP ? ((k % 2 == 0) ? k / 2 : M / 2 + k / 2) : k; }
-  static constexpr int k_of_pos(int j) { return XP ? (j < M / 2 ? 2 * j : 2 * (j - M / 2) + 1) : j; }
+  static constexpr int pos_of_k(int k) { return (k % 2 == 0) ? k / 2 : M / 2 + k / 2; }
+  static constexpr int k_of_pos(int j) { return j < M / 2 ? 2 * j : 2 * (j - M / 2) + 1; }
   static constexpr int ZSET = (S * S / 2) * BS;       // floats: one set of 32 blocks
   static constexpr int PI = 64 / M;                   // item rows per producer wave (2)
   static constexpr int PWAVES = (M + PI - 1) / PI;    // producer waves (14 for M = 28)
   static_assert(PWAVES <= NW, "producers");
   static constexpr int NROT = 3;                      // rotations of the L = 3 network
-#ifndef DCTS_T2_PIN
-#define DCTS_T2_PIN 1
-#endif
 #ifndef DCTS_T2_DMACOLS
 #define DCTS_T2_DMACOLS 2
 #endif
@@ -291,23 +277,6 @@ __device__ __forceinline__ void t2_network(float (&y)[kT2S], const float (&rc)[T
   });
 }
 
-// DCTS_T2_PRIO=2: every wave walks its issue priority through 0..3 at the stage boundaries of the leaf
-// codelets, the four waves of a SIMD (wave, wave + 4, ...) a step apart: at equal priority the arbiter
-// serves the oldest wave first and the four finish a phase one after the other (stamps: 5.0 / 6.1 / 7.9 /
-// 9.5 k cycles), the last one alone on its SIMD at a quarter of the issue rate.
-template <int K>
-__device__ __forceinline__ void t2_tick() {
-#if defined(DCTS_T2_PRIO) && DCTS_T2_PRIO == 2
-  const int g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-  switch ((g + K) & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-  }
-#endif
-}
-
 // Leaf transforms in stages, with scheduling barriers between the half-size sub-transforms and the
 // outputs handed to `sink(k, value)` as soon as a stage has them (an LDS store on axis A, a square on
 // axis B). Left to itself the machine scheduler interleaves the independent halves of a codelet for
@@ -326,21 +295,18 @@ __device__ __forceinline__ void t2_dct2_staged(const float (&x)[M], Sink sink) {
     v[n] = x[n] - x[M - 1 - n];
   });
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<0>();
   {
     float E[H];
     dcts::Dct2<H>::run(u, E);
     dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE { sink(std::integral_constant<int, 2 * decltype(i)::value>{}, E[decltype(i)::value]); });
   }
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<1>();
   {
     float O[H];
     dcts::Dct4<H>::run(v, O);
     dcts::static_for<H>([&](auto i) DCTS_LAMBDA_INLINE { sink(std::integral_constant<int, 2 * decltype(i)::value + 1>{}, O[decltype(i)::value]); });
   }
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<2>();
 }
 template <int M, class Sink>
 __device__ __forceinline__ void t2_dct4_staged(const float (&v)[M], Sink sink) {
@@ -356,14 +322,11 @@ __device__ __forceinline__ void t2_dct4_staged(const float (&v)[M], Sink sink) {
     b[n] = v[M - 1 - n] * (sg * c) - v[n] * (sg * sn);
   });
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<0>();
   float A[H], B[H];
   dcts::Dct2<H>::run(a, A);
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<1>();
   dcts::Dct2<H>::run(b, B);
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<2>();
   sink(std::integral_constant<int, 0>{}, A[0]);
   sink(std::integral_constant<int, M - 1>{}, -B[0]);
   dcts::static_for<H - 1>([&](auto i) DCTS_LAMBDA_INLINE {
@@ -372,7 +335,6 @@ __device__ __forceinline__ void t2_dct4_staged(const float (&v)[M], Sink sink) {
     sink(std::integral_constant<int, 2 * jj - 1>{}, A[jj] - B[H - jj]);
   });
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<3>();
 }
 
 // The same staged codelets with the outputs handed over in two groups of M/2: even k after the first
@@ -388,21 +350,18 @@ __device__ __forceinline__ void t2_dct2_groups(const float (&x)[M], Sink sink) {
     v[n] = x[n] - x[M - 1 - n];
   });
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<0>();
   {
     float E[H];
     dcts::Dct2<H>::run(u, E);
     sink(std::integral_constant<int, 0>{}, E);
   }
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<1>();
   {
     float O[H];
     dcts::Dct4<H>::run(v, O);
     sink(std::integral_constant<int, 1>{}, O);
   }
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<2>();
 }
 template <int M, class Sink>
 __device__ __forceinline__ void t2_dct4_groups(const float (&v)[M], Sink sink) {
@@ -417,14 +376,11 @@ __device__ __forceinline__ void t2_dct4_groups(const float (&v)[M], Sink sink) {
     b[n] = v[M - 1 - n] * (sg * c) - v[n] * (sg * sn);
   });
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<0>();
   float A[H], B[H];
   dcts::Dct2<H>::run(a, A);
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<1>();
   dcts::Dct2<H>::run(b, B);
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<2>();
   {
     float Ev[H];  // k = 0, 2, 4, ...
     Ev[0] = A[0];
@@ -435,7 +391,6 @@ __device__ __forceinline__ void t2_dct4_groups(const float (&v)[M], Sink sink) {
     sink(std::integral_constant<int, 0>{}, Ev);
   }
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<3>();
   {
     float Od[H];  // k = 1, 3, 5, ...
     dcts::static_for<H - 1>([&](auto i) DCTS_LAMBDA_INLINE {
@@ -446,7 +401,6 @@ __device__ __forceinline__ void t2_dct4_groups(const float (&v)[M], Sink sink) {
     sink(std::integral_constant<int, 1>{}, Od);
   }
   __builtin_amdgcn_sched_barrier(0);
-  t2_tick<4>();
 }
 
 typedef float t2_v4f __attribute__((ext_vector_type(4)));
@@ -489,38 +443,27 @@ struct T2Pass {
   }
 };
 
-// axis A: lane = column q', transform along p'. !XP: in place in the block's LDS image. XP: the lane's
-// outputs go to ROW q' of the block (the transposition; every lane of the wave has read its column
-// before the first store is issued - the codelets consume all inputs in their first stage and a
-// wave's LDS operations complete in order), as 16-byte pieces in the order pos_of_k.
+// axis A: lane = column q', transform along p'; the lane's outputs go to ROW q' of the block (the
+// transposition; every lane of the wave has read its column before the first store is issued - the
+// codelets consume all inputs in their first stage and a wave's LDS operations complete in order), as
+// 16-byte pieces in the order pos_of_k.
 template <int M, int TA>
 __device__ __forceinline__ void t2_axis_a(const T2Pass<M>& ps) {
-  using Cfg = T2Cfg<M>;
-  constexpr int RS = Cfg::RS;
+  constexpr int RS = T2Cfg<M>::RS;
   float in[M];
   lds_cptr src = ps.blk + (ps.act ? ps.j : 0);
   dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { in[decltype(i)::value] = src[decltype(i)::value * RS]; });
-  if constexpr (Cfg::XP) {
-    lds_ptr row = ps.blk + ps.j * RS;
-    const bool act = ps.act;
-    auto put = [&](auto half, const float (&g)[M / 2]) DCTS_LAMBDA_INLINE {
-      // exec-masked per group: the group's values are alive here anyway
-      if (act) t2_store_group<M / 2, decltype(half)::value * (M / 2)>(row, g);
-    };
-    if constexpr (TA)
-      t2_dct4_groups<M>(in, put);
-    else
-      t2_dct2_groups<M>(in, put);
-  } else {
-    // this lane's own column. Unconditional stores (idle lanes hit the pad column M < RS, which nobody
-    // reads): an exec-masked store block kept all M outputs alive at once, 62 VGPRs instead of 44
-    lds_ptr dst = ps.blk + (ps.act ? ps.j : M);
-    auto put = [&](auto k, float val) DCTS_LAMBDA_INLINE { dst[decltype(k)::value * RS] = val; };
-    if constexpr (TA)
-      t2_dct4_staged<M>(in, put);
-    else
-      t2_dct2_staged<M>(in, put);
-  }
+  lds_ptr row = ps.blk + ps.j * RS;
+  const bool act = ps.act;
+  // exec-masked per group of M/2 outputs (the group's values are alive at that point anyway; a mask
+  // around single stores kept all M outputs alive at once: 62 VGPRs instead of 44)
+  auto put = [&](auto half, const float (&g)[M / 2]) DCTS_LAMBDA_INLINE {
+    if (act) t2_store_group<M / 2, decltype(half)::value * (M / 2)>(row, g);
+  };
+  if constexpr (TA)
+    t2_dct4_groups<M>(in, put);
+  else
+    t2_dct2_groups<M>(in, put);
 }
 
 // axis B: lane = row k1, transform along q'; returns the lane's weighted energy. A mixed pass (the
@@ -533,9 +476,9 @@ __device__ __forceinline__ float t2_axis_b(const T2Pass<M>& ps, int set, float* 
   auto run = [&](auto tb, bool mine) DCTS_LAMBDA_INLINE {
     constexpr int TB = decltype(tb)::value;
     float z[M];
-    // lane = row k1 of the half-transformed block. XP: that row is column j of the transposed image
-    lds_cptr src = ps.blk + (ps.act ? ps.j : 0) * (T2Cfg<M>::XP ? 1 : RS);
-    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { z[decltype(i)::value] = src[decltype(i)::value * (T2Cfg<M>::XP ? RS : 1)]; });
+    // lane = row k1 of the half-transformed block = column j of the transposed image (k1 = k_of_pos(j))
+    lds_cptr src = ps.blk + (ps.act ? ps.j : 0);
+    dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { z[decltype(i)::value] = src[decltype(i)::value * RS]; });
     float t0 = 0.f, t1 = 0.f;
     // debug / parity path: leaf outputs, unweighted, as [ra * M + k1][rb * M + k2] (k_assemble's layout)
     float* o = nullptr;
@@ -623,21 +566,9 @@ __device__ __forceinline__ float t2_axis_b_chain(int vid, const T2Pass<M>& ps, f
   }
 }
 
-// The four waves of a SIMD (wave, wave + 4, ... of the workgroup) are arbitrated oldest first: in an
-// issue-bound phase the youngest ran at half the speed of the oldest (stamps: 8.0 k vs 4.5 k cycles
-// for the same pass) and everybody then waits for it at the barrier. Rotating a static priority
-// through the four of them at every hook point evens their progress out.
-__device__ __forceinline__ void t2_rotate_prio(int wave, int step) {
-#if defined(DCTS_T2_PRIO) && DCTS_T2_PRIO == 1  // measured neutral (the phases are issue-bound: evening the waves out moves time from the barriers into the phases), off
-  switch (((wave >> 2) + step) & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-  }
-#endif
-}
-
+// (The four waves of a SIMD - wave, wave + 4, ... - are arbitrated oldest first and finish a phase one after
+// the other, the youngest last. Rotating s_setprio through them per phase half or per codelet stage evens
+// their progress out but only moves time from the barriers into the phases: measured neutral, removed.)
 // One pass with the caller's hook at three points: before axis A, between the axes, after axis B.
 // The caller trickles the next map's loads out there: a burst of loads blocks the issuing wave until
 // the CU's miss queue has room (stamps: 10 k cycles per map for 32 loads per wave in one go, i.e. the
@@ -645,12 +576,10 @@ __device__ __forceinline__ void t2_rotate_prio(int wave, int step) {
 template <int M, int SET, bool STORE, class Hook>
 __device__ __forceinline__ float t2_consume(int vid, lds_ptr zbuf, lds_cptr params, int wave, int lane, float* leaf_out, Hook hook) {
   const T2Pass<M> ps(zbuf, params, SET, wave, lane);
-  t2_rotate_prio(wave, 2 * SET);
   hook(std::integral_constant<int, 0>{});
   __builtin_amdgcn_sched_barrier(0);
   t2_axis_a_chain<M, SET>(vid, ps);
   __builtin_amdgcn_sched_barrier(0);
-  t2_rotate_prio(wave, 2 * SET + 1);
   hook(std::integral_constant<int, 1>{});
   __builtin_amdgcn_sched_barrier(0);
   // the wave's own LDS traffic is in order; only the compiler must not reorder
@@ -832,11 +761,10 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
       dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE {
         constexpr int a = decltype(ia)::value;
         t2_network<M>(v[a], rq);
-#if DCTS_T2_PIN
         // the outputs exist HERE: LLVM otherwise sinks the networks down to the LDS stores of the set that
-        // uses them (behind the barrier, interleaved with the stores' address arithmetic: more live values)
+        // uses them (behind the barrier, interleaved with the stores' address arithmetic: 15 spilled VGPRs,
+        // and every scratch reload waits vmcnt(0), i.e. for the next map's loads as well)
         dcts::static_for<S>([&](auto ib) DCTS_LAMBDA_INLINE { t2_pin(v[a][decltype(ib)::value]); });
-#endif
         __builtin_amdgcn_sched_barrier(0);
       });
     }
@@ -850,17 +778,11 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
       bool ok;
       item_pq(p, q, ok);
       {
-        // lanes without an item store unconditionally (see t2_consume) where nobody reads: the pad column
-        // (q' = M < RS), or with XP the four pad words behind the block
-        const int qa = ok ? q : M, qd = ok ? M - 1 - q : M;
-        int o_aa = p * RS + qa, o_ad = p * RS + qd, o_da = (M - 1 - p) * RS + qa, o_dd = (M - 1 - p) * RS + qd;
-        if constexpr (Cfg::XP) {
-          const int dump = M * RS + (launder(lane_in) & 3);
-          o_aa = ok ? o_aa : dump;
-          o_ad = ok ? o_ad : dump;
-          o_da = ok ? o_da : dump;
-          o_dd = ok ? o_dd : dump;
-        }
+        // lanes without an item store unconditionally (a branch around the stores costs registers) into
+        // the four pad words behind the block, which nobody reads
+        const int dump = M * RS + (launder(lane_in) & 3);
+        const int o_aa = ok ? p * RS + q : dump, o_ad = ok ? p * RS + (M - 1 - q) : dump;
+        const int o_da = ok ? (M - 1 - p) * RS + q : dump, o_dd = ok ? (M - 1 - p) * RS + (M - 1 - q) : dump;
         dcts::static_for<S>([&](auto ia) DCTS_LAMBDA_INLINE {
           constexpr int ra = decltype(ia)::value;
           dcts::static_for<S>([&](auto ib) DCTS_LAMBDA_INLINE {

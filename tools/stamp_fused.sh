@@ -3,13 +3,20 @@
 # cycles go per phase. Run on the GPU box: tools/stamp_fused.sh [edge] [nmaps]
 set -e
 edge=${1:-224}; nmaps=${2:-4096}
-mkdir -p gpurun_out/stamps
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wno-inline-asm -fno-slp-vectorize -DDCTS_FUSED_STAMPS \
-  -o gpurun_out/stamps/libdctscore_stamps.so dct_pruning_amd/csrc/dct_kernels.hip
+# the diagnostic library: build_dev/libdctscore_stamps.so if it was built in the container (build_dev/ travels
+# with gpurun; the single-unit build takes minutes), otherwise built here
+lib=build_dev/libdctscore_stamps.so
+if [ ! -f "$lib" ]; then
+  mkdir -p gpurun_out/stamps
+  lib=gpurun_out/stamps/libdctscore_stamps.so
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wno-inline-asm -fno-slp-vectorize -DDCTS_FUSED_STAMPS \
+    -o "$lib" dct_pruning_amd/csrc/dct_kernels.hip dct_pruning_amd/csrc/tile2d.hip
+fi
+export DCTS_STAMPS_LIB="$lib"
 python3 - "$edge" "$nmaps" <<'PY'
-import ctypes, sys, torch
+import ctypes, os, sys, torch
 edge, nmaps = int(sys.argv[1]), int(sys.argv[2])
-lib = ctypes.CDLL("gpurun_out/stamps/libdctscore_stamps.so")
+lib = ctypes.CDLL(os.environ["DCTS_STAMPS_LIB"])
 i64, i32, vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p
 lib.dcts_energy_f32_ex.argtypes = [vp] + [i64] * 8 + [i32] * 3 + [vp, vp, ctypes.c_size_t, vp, i32]
 x = torch.relu(torch.randn(1, nmaps, edge, edge, device="cuda")); out = torch.empty(1, nmaps, device="cuda")
