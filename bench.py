@@ -198,10 +198,14 @@ def headline(lib, dev, stream_ptr, ws_fn):
         bufs = [synth(1, nmaps, h, h, 777 + i, dev) for i in range(nbuf)]
         ws = ws_fn(1, nmaps, h, h)
         units = [BoundUnit(lib, b, False, stream_ptr, ws) for b in bufs]
-        for u in units:
-            u.launch_energy()
+        # >= 20 warm-up + >= 100 timed launches, median and min. The length matters for
+        # the large tiles: under sustained load the clock management first drops, then raises the shader
+        # clock (224x224, 4096 maps: 225 us -> 300 us after ~10 launches -> 215 us from launch ~90 on,
+        # profiles/r02_rep_times_dvfs.txt); ten launches measured the dip
+        for i in range(20):
+            units[i % nbuf].launch_energy()
         torch.cuda.synchronize(dev)
-        reps = 30 if h < 72 else 10
+        reps = 100
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for i in range(reps):
             ev[i][0].record()

@@ -100,6 +100,13 @@ struct CodeletCfg {
   static constexpr int WAVE_LDS = G * MAP_LDS;  // floats per wave
   // waves per workgroup: keep a workgroup's slab <= 48 KiB so >= 3 workgroups fit a CU
   static constexpr int WAVES = (WAVE_LDS * 4 * 4 <= 49152) ? 4 : ((WAVE_LDS * 4 * 2 <= 49152) ? 2 : 1);
+  // Waves launched per CU at most (the grid-stride loop takes the rest). NOT one residency (12 waves per CU
+  // at 56 x 56): a grid several times the residency, whose workgroups the dispatcher hands out as CUs free up,
+  // is faster than persistent waves in lock step - sweep of this cap on the bench's own launches, waves per
+  // CU -> % of the HBM peak: 56 x 56 (344 k maps) 32: 67.2, 128...512: 69.6, 2048: 66.3; 28 x 28 (819 k) 32:
+  // 68.4, 256: 74.7, 512: 76.4, 2048: 72.5; 14 x 14 (2.4 M) 32: 69.4, 512: 74.7, 2048: 74.9; 200 MB launches
+  // of 8 / 14 / 28 / 32: 62 -> 71, 62 -> 71, 66 -> 72.5, 68 -> 73.5; whole ResNet-50 step 3259 -> 3561 Mmaps/s.
+  static constexpr int GRID_WAVES_PER_CU = (HP * WP >= 48 * 48) ? 256 : 512;
 };
 
 // one group of G maps: both passes, the LDS transpose and the reduction (see the header comment)
@@ -1880,7 +1887,7 @@ int launch_codelet(const MapGeom& g, float* out, hipStream_t st) {
   using Cfg = CodeletCfg<HP, WP>;
   const long long ngroups = (g.nmaps + Cfg::G - 1) / Cfg::G;
   long long blocks = (ngroups + Cfg::WAVES - 1) / Cfg::WAVES;
-  const long long cap = (long long)num_cus() * 32 / Cfg::WAVES;  // one full residency of waves
+  const long long cap = (long long)num_cus() * Cfg::GRID_WAVES_PER_CU / Cfg::WAVES;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_energy_codelet<HP, WP, PAD, STORE>), dim3((unsigned)blocks),
@@ -2278,7 +2285,7 @@ template <int HP, int WP, int PAD>
 int launch_codelet_multi(const MultiGeom& mg, hipStream_t st) {
   using Cfg = CodeletCfg<HP, WP>;
   long long blocks = (mg.total_groups + Cfg::WAVES - 1) / Cfg::WAVES;
-  const long long cap = (long long)num_cus() * 32 / Cfg::WAVES;
+  const long long cap = (long long)num_cus() * Cfg::GRID_WAVES_PER_CU / Cfg::WAVES;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL((k_energy_codelet_multi<HP, WP, PAD>), dim3((unsigned)blocks), dim3(64 * Cfg::WAVES), 0, st,
