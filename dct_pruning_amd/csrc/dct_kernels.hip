@@ -106,7 +106,9 @@ struct CodeletCfg {
   // CU -> % of the HBM peak: 56 x 56 (344 k maps) 32: 67.2, 128...512: 69.6, 2048: 66.3; 28 x 28 (819 k) 32:
   // 68.4, 256: 74.7, 512: 76.4, 2048: 72.5; 14 x 14 (2.4 M) 32: 69.4, 512: 74.7, 2048: 74.9; 200 MB launches
   // of 8 / 14 / 28 / 32: 62 -> 71, 62 -> 71, 66 -> 72.5, 68 -> 73.5; whole ResNet-50 step 3259 -> 3561 Mmaps/s.
-  static constexpr int GRID_WAVES_PER_CU = (HP * WP >= 48 * 48) ? 256 : 512;
+  // (4 x 4 and 2 x 2 groups are 1 KB and 512 B: there the wider grid costs more in wave launches than it
+  // gains - 70 -> 61 % and 50 -> 46 % - and the cap stays at 32.)
+  static constexpr int GRID_WAVES_PER_CU = (HP * WP >= 48 * 48) ? 256 : ((HP * WP >= 8 * 8) ? 512 : 32);
 };
 
 // one group of G maps: both passes, the LDS transpose and the reduction (see the header comment)
