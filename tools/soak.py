@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Soak for races: the pipelined and lane-per-map kernels on random map counts, twice each (must be
-bit-identical) and against sum(x^2) (Parseval, 1e-5). usage: tools/soak.py [iterations]"""
+"""Soak for races: the 2-D split, pipelined, fused and lane-per-map kernels and the wide-grid codelet kernels
+on random map counts, twice each (must be bit-identical) and against sum(x^2) (Parseval, 1e-5).
+usage: tools/soak.py [iterations]"""
 import os
 import sys
 
@@ -16,7 +17,8 @@ bad = 0
 for it in range(iters):
     edge, algo, hi = [(224, dpa.ALGO_PIPE, 1500), (128, dpa.ALGO_PIPE, 4000), (7, dpa.ALGO_LANE, 300000),
                       (9, dpa.ALGO_LANE, 200000), (224, dpa.ALGO_FUSED, 1500), (256, dpa.ALGO_FUSED, 1200), (288, dpa.ALGO_FUSED, 900),
-                      (320, dpa.ALGO_FUSED, 700)][it % 8]
+                      (320, dpa.ALGO_FUSED, 700), (224, dpa.ALGO_TILE2D, 3000), (224, dpa.ALGO_TILE2D, 700),
+                      (56, dpa.ALGO_AUTO, 60000), (28, dpa.ALGO_AUTO, 200000), (14, dpa.ALGO_AUTO, 600000)][it % 13]
     nmaps = int(rng.integers(1, hi))
     x = torch.relu(torch.randn(1, nmaps, edge, edge, device="cuda"))
     a = dpa.energy_nc(x, algo=algo)
