@@ -1203,6 +1203,10 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
   long long pending_m = -1;
   long long m = blockIdx.x;
   const long long nmaps = tb.total;
+#ifdef DCTS_FUSED_STAMPS
+  unsigned long long acc_[16] = {}, last_;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+#endif
   auto finish = [&](lds_ptr part, int slot, long long mm) DCTS_LAMBDA_INLINE {
     if (W == 0 && lane_in == 0) {
       float t = 0.f;
@@ -1223,8 +1227,11 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
       constexpr int s = decltype(is)::value;
+      DCTS_STAMP(11);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this strip has landed
+      DCTS_STAMP(0);
       lds_barrier();                                     // ... for everyone; the other buffer is free
+      DCTS_STAMP(1);
       if constexpr (s == 0) {
         if (pending_m >= 0) {
           finish(partials, pending_slot, pending_m);
@@ -1242,12 +1249,16 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
       }
       int lane = launder(lane_in);
       const bool act = s * SW + lane < N;
+      DCTS_STAMP(2);
       split_butterflies<M, L, NoHook, false, NW>(buf, SW, act, lane, W);
+      DCTS_STAMP(3);
       if (more) {
 #pragma unroll
         for (int it = 1; it < Stage::PIECES; it += 2) Stage::piece_raw(nsrc, nstrip, nxt, launder(lane_in), W, it);
       }
+      DCTS_STAMP(2);
       lds_barrier();
+      DCTS_STAMP(4);
       lane = launder(lane_in);
       dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
         constexpr int i = decltype(ii)::value;
@@ -1260,6 +1271,7 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
           parked[i][s][k] = o[k];
         });
       });
+      DCTS_STAMP(5);
       cur ^= 1;
     });
     // ---- pass 2: W axis, KPR coefficients of every role per round ---------------------------
@@ -1267,7 +1279,9 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
     float e = 0.f;
     dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(ir)::value;
+      DCTS_STAMP(11);
       lds_barrier();  // previous readers of blk are done
+      DCTS_STAMP(6);
       int lane = launder(lane_in);
       dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
         constexpr int i = decltype(ii)::value;
@@ -1285,11 +1299,15 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
           });
         });
       });
+      DCTS_STAMP(7);
       lds_barrier();
+      DCTS_STAMP(8);
       lane = launder(lane_in);
       const bool colact = lane < COLS;
       split_butterflies<M, L, NoHook, false, NW>(blk, RW, colact, lane, W);
+      DCTS_STAMP(9);
       lds_barrier();
+      DCTS_STAMP(10);
       dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
         constexpr int i = decltype(ii)::value;
         const int ln = launder(lane_in);
@@ -1310,6 +1328,7 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
         asm volatile("" : "+v"(er));
         if (ln < COLS) e += er;
       });
+      DCTS_STAMP(12);
     });
     e = wave_sum_dpp(e);
     if constexpr (Cfg::DEFER) {
@@ -1331,6 +1350,10 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
     lds_barrier();
     finish(partials, pending_slot, pending_m);
   }
+#ifdef DCTS_FUSED_STAMPS
+  if (lane_in == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&g_fused_stamps[W][i], acc_[i]);
+#endif
 }
 
 template <int M, int L, bool STORE, int... Wv>
