@@ -414,155 +414,103 @@ def load_google_model(state_dict, oristate_dict, imp, modules, filters=None):
 
 
 def load_u2netp_model(state_dict, oristate_dict, imp, conv_names):
-    """utils/load_models.py:585-769. `conv_names`: the Conv2d modules in named_modules() order (the
-    loop breaks at 'outconv', :598-599); `imp`: {file stem without '.npy': array} for
-    args.imp_score + '/net.stage<k>[d].<unit>.relu_s1.npy' and '/net.side<k>.npy'. The reference's
-    own failure modes are kept: `list(None)` when a stage starts while no index is live (:617, :621),
-    `int('i')` for an un-pruned decoder rebnconvin behind a pruned layer (:658) and indexing a None
-    entry of save_select_index raise here exactly as they do there."""
-    last_select_index = None  # :587
-    cnt = 0  # :589
-    stage_id = 1  # :590
-    save_select_index = []  # :591
-    save_stage_select_index = []  # :592
-    save_side_select_index = []  # :593
+    """utils/load_models.py:585-769, element by element. `conv_names`: the Conv2d modules in named_modules()
+    order (the loop stops at 'outconv', :598-599); `imp`: {file stem without '.npy': array} for
+    args.imp_score + '/net.stage<k>[d].<unit>.relu_s1.npy' and '/net.side<k>.npy'.
 
-    def rank_of(stage_id, flag, midfix):  # :629-630 and its repeats
-        return imp['net.stage' + str(stage_id) + flag + midfix + '.relu_s1']
+    The reference spells the same two scalar-slice loops out nine times; here they are the helpers `rows_cols`
+    (dst[ri][cj + col0] = src[r][c + src_off]) and `whole_rows`, called from the same branch structure. The
+    reference's own failure modes are kept: list(None) when a stage starts while no index is live (:617, :621),
+    int('i') for an un-pruned decoder rebnconvin behind a pruned layer (:658), indexing a None entry of
+    save_select_index."""
+    last = None                      # last_select_index, :587
+    side_cnt, stage_id = 0, 1        # cnt, stage_id, :589-590
+    in_unit, per_stage, per_side = [], [], []   # save_select_index, save_stage_select_index, save_side_select_index
 
-    for name in conv_names:  # :595-601
-        if name == 'outconv':
+    def rank(key):
+        return imp[key]
+
+    def kept(key, o, c):             # :629-632 and its eight repeats
+        idx = np.argsort(rank(key))[o - c:]
+        idx.sort()
+        return idx
+
+    def rows_cols(dst, src, row_pairs, cols, col0=0, src_off=0):
+        for ri, r in row_pairs:
+            for cj, cc in enumerate(cols):
+                dst[ri][cj + col0] = src[r][cc + src_off]
+
+    def whole_rows(dst, src, row_pairs):
+        for ri, r in row_pairs:
+            dst[ri] = src[r]
+
+    for name in conv_names:
+        if name == 'outconv':        # :598-599
             break
-        side_name = name.split('.')[0]  # :602
-        decode = True if side_name[-1] == 'd' else False  # :603
-        flag = '.' if not decode else 'd.'  # :604
-        midfix = name.split('.')[1] if not side_name[:4] == 'side' else None  # :607
-        oriweight = oristate_dict[name + '.weight']  # :609
-        curweight = state_dict[name + '.weight']  # :610
-        orifilter_num = oriweight.size(0)  # :611
-        currentfilter_num = curweight.size(0)  # :612
-        oriin_num = oriweight.size(1)  # :613
-        cov_id = midfix[-2:] if not side_name[:4] == 'side' else None  # :615
-        if decode == True and side_name[-2] != str(stage_id):  # :616
+        top = name.split('.')[0]     # side_name, :602
+        decode = top[-1] == 'd'      # :603
+        is_side = top[:4] == 'side'
+        unit = None if is_side else name.split('.')[1]   # midfix, :607
+        tag = None if is_side else unit[-2:]             # cov_id, :615
+        key = name + '.weight'
+        src, dst = oristate_dict[key], state_dict[key]
+        o, c, half = src.size(0), dst.size(0), int(src.size(1) / 2)   # :611-613, int(oriin_num/2)
+        if decode and top[-2] != str(stage_id):          # :616-619
             stage_id -= 1
-            save_side_select_index.append(list(last_select_index))
-            save_select_index = []
-        elif decode == False and side_name[-1] != str(stage_id):  # :620
+            per_side.append(list(last))
+            in_unit = []
+        elif (not decode) and top[-1] != str(stage_id):  # :620-623
             stage_id += 1
-            save_stage_select_index.append(list(last_select_index))
-            save_select_index = []
+            per_stage.append(list(last))
+            in_unit = []
+        score_key = None if is_side else 'net.stage%d%s%s.relu_s1' % (stage_id, 'd.' if decode else '.', unit)
 
-        if midfix != None:  # :625
-            if decode == True and cov_id == 'in':  # :627
-                if orifilter_num != currentfilter_num:  # :628
-                    rank = rank_of(stage_id, flag, midfix)
-                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
-                    select_index.sort()
-                    for index_i, i in enumerate(select_index):  # :634-640
-                        for index_j, j in enumerate(last_select_index):
-                            state_dict[name + '.weight'][index_i][index_j] = \
-                                oristate_dict[name + '.weight'][i][j]
-                        for index_k, k in enumerate(save_stage_select_index[stage_id - 1]):
-                            state_dict[name + '.weight'][index_i][index_k + len(last_select_index)] = \
-                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
-                    last_select_index = select_index  # :642
-                    save_select_index.append(list(select_index))
-                elif last_select_index is not None:  # :645
-                    rank = rank_of(stage_id, flag, midfix)
-                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
-                    select_index.sort()
-                    for i in range(orifilter_num):  # :651-657
-                        for index_j, j in enumerate(last_select_index):
-                            state_dict[name + '.weight'][i][index_j] = \
-                                oristate_dict[name + '.weight'][i][j]
-                        for index_k, k in enumerate(save_select_index[int(cov_id[0])]):
-                            state_dict[name + '.weight'][i][index_k + len(last_select_index)] = \
-                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
-                    last_select_index = select_index
-                    save_select_index.append(list(select_index))
-                else:  # :662
-                    state_dict[name + '.weight'] = oriweight
-                    last_select_index = None
-                    save_select_index.append(None)
-            elif cov_id[1] != 'd':  # :667
-                if orifilter_num != currentfilter_num:
-                    rank = rank_of(stage_id, flag, midfix)
-                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
-                    select_index.sort()
-                    if last_select_index is not None:  # :674
-                        for index_i, i in enumerate(select_index):
-                            for index_j, j in enumerate(last_select_index):
-                                state_dict[name + '.weight'][index_i][index_j] = \
-                                    oristate_dict[name + '.weight'][i][j]
-                    else:  # :679
-                        for index_i, i in enumerate(select_index):
-                            state_dict[name + '.weight'][index_i] = \
-                                oristate_dict[name + '.weight'][i]
-                    last_select_index = select_index
-                    save_select_index.append(list(select_index))
-                elif last_select_index is not None:  # :687
-                    rank = rank_of(stage_id, flag, midfix)
-                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
-                    select_index.sort()
-                    for i in range(orifilter_num):
-                        for index_j, j in enumerate(last_select_index):
-                            state_dict[name + '.weight'][i][index_j] = \
-                                oristate_dict[name + '.weight'][i][j]
-                    last_select_index = select_index
-                    save_select_index.append(list(select_index))
-                else:  # :701
-                    state_dict[name + '.weight'] = oriweight
-                    last_select_index = None
-                    save_select_index.append(None)
-            else:  # :706  rebnconv<k>d
-                if orifilter_num != currentfilter_num:
-                    rank = rank_of(stage_id, flag, midfix)
-                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
-                    select_index.sort()
-                    for index_i, i in enumerate(select_index):  # :713-719
-                        for index_j, j in enumerate(last_select_index):
-                            state_dict[name + '.weight'][index_i][index_j] = \
-                                oristate_dict[name + '.weight'][i][j]
-                        for index_k, k in enumerate(save_select_index[int(cov_id[0])]):
-                            state_dict[name + '.weight'][index_i][index_k + len(last_select_index)] = \
-                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
-                    last_select_index = select_index
-                elif last_select_index is not None:  # :723
-                    rank = rank_of(stage_id, flag, midfix)
-                    select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
-                    select_index.sort()
-                    for i in range(orifilter_num):
-                        for index_j, j in enumerate(last_select_index):
-                            state_dict[name + '.weight'][i][index_j] = \
-                                oristate_dict[name + '.weight'][i][j]
-                        for index_k, k in enumerate(save_select_index[int(cov_id[0])]):
-                            state_dict[name + '.weight'][i][index_k + len(last_select_index)] = \
-                                oristate_dict[name + '.weight'][i][k + int(oriin_num / 2)]
-                    last_select_index = select_index
-                else:  # :738
-                    state_dict[name + '.weight'] = oriweight
-                    last_select_index = None
-        else:  # :742  side<k>
-            cnt += 1
-            if orifilter_num != currentfilter_num:
-                rank = imp['net.side%d' % cnt]
-                select_index = np.argsort(rank)[orifilter_num - currentfilter_num:]
-                select_index.sort()
-                if last_select_index is not None:
-                    for index_i, i in enumerate(select_index):
-                        for index_j, j in enumerate(last_select_index):
-                            state_dict[name + '.weight'][index_i][index_j] = \
-                                oristate_dict[name + '.weight'][i][j]
+        if not is_side:
+            # which second input half the conv has: the encoder stage's output (decoder rebnconvin, :627),
+            # none (rebnconvin of an encoder stage and rebnconv<k>, :667), the unit's own rebnconv<k> (rebnconv<k>d, :706)
+            kind = 'stage' if (decode and tag == 'in') else ('none' if tag[1] != 'd' else 'unit')
+            if o != c:
+                sel = kept(score_key, o, c)
+                pairs = list(enumerate(sel))
+                if kind == 'none':
+                    if last is not None:                 # :674-678
+                        rows_cols(dst, src, pairs, last)
+                    else:                                # :679-682
+                        whole_rows(dst, src, pairs)
+                else:                                    # :634-640, :713-719
+                    rows_cols(dst, src, pairs, last)
+                    other = per_stage[stage_id - 1] if kind == 'stage' else in_unit[int(tag[0])]
+                    rows_cols(dst, src, pairs, other, col0=len(last), src_off=half)
+                last = sel
+                if kind != 'unit':
+                    in_unit.append(list(sel))            # :643, :685
+            elif last is not None:
+                sel = kept(score_key, o, c)              # read although nothing is pruned here (:646-649, :688-691, :724-727)
+                pairs = [(r, r) for r in range(o)]
+                rows_cols(dst, src, pairs, last)
+                if kind != 'none':
+                    other = in_unit[int(tag[0])]         # :658 uses cov_id[0] for 'in' as well -> ValueError
+                    rows_cols(dst, src, pairs, other, col0=len(last), src_off=half)
+                last = sel
+                if kind != 'unit':
+                    in_unit.append(list(sel))
+            else:                                        # :662-665, :701-704, :738-740
+                state_dict[key] = src
+                last = None
+                if kind != 'unit':
+                    in_unit.append(None)
+        else:                                            # :742-767
+            side_cnt += 1
+            if o != c:
+                sel = kept('net.side%d' % side_cnt, o, c)
+                pairs = list(enumerate(sel))
+                if last is not None:
+                    rows_cols(dst, src, pairs, last)
                 else:
-                    for index_i, i in enumerate(select_index):
-                        state_dict[name + '.weight'][index_i] = \
-                            oristate_dict[name + '.weight'][i]
-            elif last_select_index is not None:  # :758
-                for i in range(orifilter_num):
-                    for index_j, j in enumerate(last_select_index):
-                        state_dict[name + '.weight'][i][index_j] = \
-                            oristate_dict[name + '.weight'][i][j]
-            else:  # :764
-                state_dict[name + '.weight'] = oriweight
-            last_select_index = save_side_select_index[5 - cnt]  # :767
+                    whole_rows(dst, src, pairs)
+            elif last is not None:
+                rows_cols(dst, src, [(r, r) for r in range(o)], last)
+            else:
+                state_dict[key] = src
+            last = per_side[5 - side_cnt]                # :767
     return state_dict
