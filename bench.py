@@ -264,10 +264,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from dct_pruning_amd import sharding as _sh
+        # bounded bring-up: a rank that cannot reach the others prints {"error": ...} and exits 3 (sharding.py)
+        _sh.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world, device=dev, what="bench.py")
 
     from dct_pruning_amd import _lib, schedules, sharding
     from dct_pruning_amd.ops import _workspace
@@ -287,7 +286,7 @@ def main():
     total_cost = sum(c * k for c, k in zip(chans, cost_pc))
     # whole hook points (layers) are the units; wide layers are only cut into channel ranges when
     # there are too few layers per rank for LPT to balance (49 layers over 8 ranks: 2.3 % imbalance)
-    split = (total_cost / (world * 3)) if world * 4 > len(points) else None
+    split = (total_cost / (world * 8)) if world * 4 > len(points) else None  # as harness.imp_score's single-sweep modes
     units = sharding.make_units(chans, cost_pc, max_unit_cost=split)
     owner, load = sharding.assign(units, world)
     off, seg = sharding.layout(units, owner, world)

@@ -9,7 +9,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdctscore.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lock = threading.Lock()
 _lib = None
@@ -23,6 +23,7 @@ SIGNATURES = {
     "dcts_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64]),
     "dcts_has_codelet": (ctypes.c_int, [_i64, _i64]),
     "dcts_workspace_invalidate": (None, [_vp]),
+    "dcts_workspace_invalidate_range": (None, [_vp, _sz]),
     "dcts_energy_f32": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                        _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "dcts_energy_f32_ex": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,

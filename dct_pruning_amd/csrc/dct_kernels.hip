@@ -2454,11 +2454,15 @@ int dispatch_tile_family(int fam, int HP, const TileBatch& tb, hipStream_t st) {
 
 // The direct kernel's basis tables live at the head of the caller's workspace. They are built once per
 // (workspace, stream, H', W') and reused by later calls: the library remembers - on the host, nothing is read
-// back - what it last left in a workspace, and forgets it whenever another of its paths writes there (the
-// split path's intermediate, the coefficient path's leaf outputs) or the caller says so
-// (dcts_workspace_invalidate). Same stream only: that is what orders the build before the reuse.
+// back - which BYTE RANGE of which workspace holds tables, and forgets an entry whenever any of its own paths
+// is about to write bytes that overlap that range (another shape's tables, the direct kernel's T tiles, the
+// split path's intermediate, the coefficient path's leaf outputs, the weighted path's coefficient chunk) or the
+// caller says so (dcts_workspace_invalidate[_range]). Same stream only: that is what orders the build before
+// the reuse. Calls that receive an INTERIOR pointer of a caller's workspace (the weighted path's inner calls)
+// never cache: an interior offset depends on the tile shape, and the caller cannot name it to invalidate it.
 struct BasisSlot {
-  void* ws;
+  uintptr_t lo, hi;  // bytes [lo, hi) hold the two tables
+  void* ws;          // the workspace pointer the call was made with
   void* stream;
   int HP, WP;
 };
@@ -2470,20 +2474,32 @@ std::mutex g_basis_mu;
 bool basis_cached(void* ws, void* stream, int HP, int WP) {
   std::lock_guard<std::mutex> lk(g_basis_mu);
   for (const BasisSlot& b : g_basis)
-    if (b.ws == ws && b.stream == stream && b.HP == HP && b.WP == WP) return true;
+    if (b.hi && b.ws == ws && b.stream == stream && b.HP == HP && b.WP == WP) return true;
   return false;
 }
+// forget every entry whose tables overlap [p, p + bytes)
+void basis_forget_range(const void* p, size_t bytes) {
+  if (!p || !bytes) return;
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+  std::lock_guard<std::mutex> lk(g_basis_mu);
+  for (BasisSlot& b : g_basis)
+    if (b.hi && b.lo < hi && lo < b.hi) b = BasisSlot{};
+}
+// the caller names a workspace by its base pointer only: forget what was cached under that pointer and
+// whatever tables contain that address
 void basis_forget(void* ws) {
   if (!ws) return;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ws);
   std::lock_guard<std::mutex> lk(g_basis_mu);
   for (BasisSlot& b : g_basis)
-    if (b.ws == ws) b = BasisSlot{};
+    if (b.hi && (b.ws == ws || (b.lo <= a && a < b.hi))) b = BasisSlot{};
 }
-void basis_remember(void* ws, void* stream, int HP, int WP) {
+void basis_remember(void* ws, const void* tables, size_t table_bytes, void* stream, int HP, int WP) {
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(tables), hi = lo + table_bytes;
   std::lock_guard<std::mutex> lk(g_basis_mu);
   for (BasisSlot& b : g_basis)
-    if (b.ws == ws) b = BasisSlot{};  // one shape per workspace: the tables overwrite each other
-  g_basis[g_basis_next] = BasisSlot{ws, stream, HP, WP};
+    if (b.hi && (b.ws == ws || (b.lo < hi && lo < b.hi))) b = BasisSlot{};  // one shape per workspace, no overlapping tables
+  g_basis[g_basis_next] = BasisSlot{lo, hi, ws, stream, HP, WP};
   g_basis_next = (g_basis_next + 1) % kBasisSlots;
 }
 
@@ -2491,7 +2507,7 @@ template <bool STORE>
 int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_t strideN,
         int64_t strideC, int64_t strideH, int64_t strideW, int32_t c_begin, int32_t c_count,
         int32_t pad_front_if_odd, float* out, void* workspace, size_t workspace_bytes,
-        void* stream, int32_t algo) {
+        void* stream, int32_t algo, bool cache_basis = true) {
   if (!x || !out) return DCTS_E_NULL;
   if (N <= 0 || C_total <= 0 || H <= 0 || W <= 0) return DCTS_E_SHAPE;
   if (c_count <= 0 || c_begin < 0 || (int64_t)c_begin + c_count > C_total) return DCTS_E_CHANNELS;
@@ -2573,7 +2589,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       const SplitWs sws = split_ws(g.nmaps, (int)HP);
       if (!workspace || workspace_bytes < sws.total) return DCTS_E_WORKSPACE;
       if (reinterpret_cast<uintptr_t>(workspace) & 15) return DCTS_E_ALIGN;  // pass 2 stages the intermediate the same way
-      basis_forget(workspace);
+      basis_forget_range(workspace, sws.total);
       return dispatch_split((int)HP, g, out, workspace, st);
     }
   } else {
@@ -2589,7 +2605,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       if (ws_maps < 1 || (reinterpret_cast<uintptr_t>(workspace) & 15)) return DCTS_E_WORKSPACE;
       const float* x0 = x + (long long)c_begin * strideC;
       float* scratch = reinterpret_cast<float*>(workspace);
-      basis_forget(workspace);
+      basis_forget_range(workspace, workspace_bytes);
       if (algo == DCTS_ALGO_TILE2D) return dctsi::dispatch_tile2d_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
       if (has_fused2(HP)) return dctsi::dispatch_fused2_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
       return dctsi::dispatch_fused_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
@@ -2603,10 +2619,14 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   float* CHt = reinterpret_cast<float*>(wsp + ws.off_ch);
   float* CWt = reinterpret_cast<float*>(wsp + ws.off_cw);
   float* T = reinterpret_cast<float*>(wsp + ws.off_t);
-  if (!basis_cached(workspace, stream, (int)HP, (int)WP)) {
+  if (!cache_basis || !basis_cached(workspace, stream, (int)HP, (int)WP)) {
+    basis_forget_range(workspace, ws.total);  // whatever tables lay in the bytes this call uses are gone
     hipLaunchKernelGGL(k_basis, dim3((unsigned)((HP * HP + 255) / 256)), dim3(256), 0, st, CHt, (int)HP);
     hipLaunchKernelGGL(k_basis, dim3((unsigned)((WP * WP + 255) / 256)), dim3(256), 0, st, CWt, (int)WP);
-    if (hipGetLastError() == hipSuccess) basis_remember(workspace, stream, (int)HP, (int)WP);
+    if (cache_basis && hipGetLastError() == hipSuccess)
+      basis_remember(workspace, wsp + ws.off_ch, ws.off_t - ws.off_ch, stream, (int)HP, (int)WP);
+  } else {
+    basis_forget_range(wsp + ws.off_t, ws.total - ws.off_t);  // the T tiles may cover another entry's tables
   }
   hipLaunchKernelGGL((k_energy_direct<STORE>), dim3((unsigned)ws.grid), dim3(kDirectThreads), 0, st,
                      g, pad, CHt, CWt, T, out);
@@ -2651,6 +2671,11 @@ size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W) {
 int dcts_has_codelet(int64_t H, int64_t W) { return has_codelet(H, W) ? 1 : 0; }
 
 void dcts_workspace_invalidate(void* workspace) { basis_forget(workspace); }
+
+void dcts_workspace_invalidate_range(void* workspace, size_t bytes) {
+  basis_forget(workspace);
+  basis_forget_range(workspace, bytes);
+}
 
 int dcts_energy_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W,
                        int64_t strideN, int64_t strideC, int64_t strideH, int64_t strideW,
@@ -2721,6 +2746,10 @@ int dcts_weighted_energy_f32(const float* x, int64_t N, int64_t C_total, int64_t
   void* inner = wsp + align_up((size_t)(chunk * tile), 256);
   const size_t inner_bytes = workspace_bytes - align_up((size_t)(chunk * tile), 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // this call writes coefficients and scratch all over the workspace: no table cached in it survives, and the
+  // inner calls (interior pointer, offset depends on the tile shape) do not cache theirs
+  basis_forget(workspace);
+  basis_forget_range(workspace, workspace_bytes);
   // the large-tile kernels where the tensor suits them, else whatever AUTO picks (codelet / direct)
   // (every inner call covers channels of ONE sample, so the batch stride does not matter)
   const bool dense = pad == 0 && H == W && strideH == W && strideW == 1 && strideC == H * W && (strideN * 4) % 16 == 0 &&
@@ -2732,7 +2761,7 @@ int dcts_weighted_energy_f32(const float* x, int64_t N, int64_t C_total, int64_t
     for (long long c0 = 0; c0 < per_sample; c0 += chunk) {
       const long long nc = (per_sample - c0) < chunk ? (per_sample - c0) : chunk;
       int rc = run<true>(x + n * strideN, 1, C_total, H, W, strideN, strideC, strideH, strideW, (int32_t)(c_begin + c0), (int32_t)nc,
-                         pad_front_if_odd, coeff, inner, inner_bytes, stream, algo);
+                         pad_front_if_odd, coeff, inner, inner_bytes, stream, algo, /*cache_basis=*/false);
       if (rc) return rc;
       long long blocks = (nc * 64 + 255) / 256;
       if (blocks > 4096) blocks = 4096;

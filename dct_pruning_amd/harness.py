@@ -157,33 +157,57 @@ def _save(out_dir, net_name, pt, scores):
 
 class _PointHook:
     """A hook with its own accumulator (single-sweep / device modes). With `batch` set, the
-    device-side update is deferred and fused across hook points (DeviceBatchAccumulator)."""
+    device-side update is deferred and fused across hook points (DeviceBatchAccumulator).
 
-    def __init__(self, kind, accumulate, device, batch=None, key=None, deferred=False):
+    `ranges` (multi-GPU, single-sweep modes): the channel ranges [(key, lo, hi), ...] of this hook point's
+    scored channels that THIS rank owns (sharding.make_units cuts wide layers so that eight ranks balance);
+    None = the whole hook point under `key`. Per-channel scores do not depend on which call computes them,
+    so the pieces concatenate to the unsplit result bit for bit."""
+
+    def __init__(self, kind, accumulate, device, batch=None, key=None, deferred=False, ranges=None, nominal_c=None):
         self.kind, self.accumulate, self.device, self.acc = kind, accumulate, device, None
         self.batch, self.key, self.deferred = batch, key, deferred
+        self.ranges, self.nominal_c, self.accs = ranges, nominal_c, {}
+
+    def _pieces(self, x):
+        """(key, c_begin, c_count, pad_front_if_odd) of every operator call this hook makes on x."""
+        b = x.shape[1]
+        base, count = (b - 12, 12) if self.kind == "last12" else (0, b)
+        pad = self.kind != "full"
+        if self.ranges is None:
+            return [(self.key, base, count, pad)]
+        if count != self.nominal_c:
+            raise RuntimeError(
+                "channel-range sharding cut this hook point by the schedule's channel count (%d) but the hooked "
+                "tensor has %d: run pruned / non-standard nets without --single_sweep under torch.distributed"
+                % (self.nominal_c, count))
+        return [(k, base + lo, hi - lo, pad) for k, lo, hi in self.ranges]
 
     def __call__(self, module, inputs, output):
-        if self.deferred and self.batch is not None:
-            x = _scored_tensor(self.kind, inputs, output)
-            b = x.shape[1]
-            if self.kind == "last12":
-                self.batch.add_tensor(self.key, x, b - 12, 12, True)
-            else:
-                self.batch.add_tensor(self.key, x, 0, b, self.kind == "input")
-            return
-        e = _hook_energy(self.kind, _scored_tensor(self.kind, inputs, output))
-        if self.batch is not None:
-            self.batch.add(self.key, e)
-            return
-        if self.acc is None:
-            self.acc = DeviceAccumulator(e.shape[1], e.device) if self.accumulate == "device" else HostAccumulator()
-        self.acc.update(e)
+        x = _scored_tensor(self.kind, inputs, output)
+        if self.ranges is None and not (self.deferred and self.batch is not None):
+            pieces = [(self.key, None, None, None)]  # the reference's own three calls, argument for argument
+        else:
+            pieces = self._pieces(x)
+        for key, cb, cc, pad in pieces:
+            if self.deferred and self.batch is not None:
+                self.batch.add_tensor(key, x, cb, cc, pad)
+                continue
+            e = _hook_energy(self.kind, x) if cb is None else _energy_nc(x, c_begin=cb, c_count=cc, pad_front_if_odd=pad)
+            if self.batch is not None:
+                self.batch.add(key, e)
+                continue
+            acc = self.accs.get(key)
+            if acc is None:
+                acc = self.accs[key] = (DeviceAccumulator(e.shape[1], e.device) if self.accumulate == "device"
+                                        else HostAccumulator())
+            acc.update(e)
 
-    def scores(self):
+    def scores(self, key=None):
+        key = self.key if key is None else key
         if self.batch is not None:
-            return np.ascontiguousarray(self.batch.scores(self.key), dtype=np.float32)
-        return np.ascontiguousarray(self.acc.scores(), dtype=np.float32)
+            return np.ascontiguousarray(self.batch.scores(key), dtype=np.float32)
+        return np.ascontiguousarray(self.accs[key].scores(), dtype=np.float32)
 
 
 def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host", group=None, deferred=False):
@@ -218,80 +242,122 @@ def imp_score(net, args, train_loader=None, single_sweep=False, accumulate="host
     sweep = u2netp_inference if args.net == "u2netp" else inference
     dev = _net_device(net)
 
-    # which hook points are mine (all of them on one GPU)
-    if world > 1:
-        units = sharding.make_units([1] * len(pts), [float(p.C * p.H * p.W) for p in pts])
-        owner, _ = sharding.assign(units, world)
-    else:
-        owner = [0] * len(pts)
-    mine = [i for i in range(len(pts)) if owner[i] == rank]
-    results = {}
-
     if deferred:
         single_sweep, accumulate = True, "device"
+
+    # Work units and their owners. A unit is a hook point, or - in the single-sweep modes, where every rank
+    # runs the one forward sweep anyway and only the scoring is divisible - a channel range of a wide hook
+    # point (sharding.make_units): VGG-16-bn has 12 hook points and GoogLeNet 10, fewer than LPT needs to
+    # balance eight ranks. In the reference's one-sweep-per-hook-point schedule a hook point stays whole:
+    # cutting it would repeat its forward sweep on another rank.
+    scored = [schedules.scored_shape(p) for p in pts]
+    chans = [sc[1] for sc in scored]
+    cost_pc = [float(p.H * p.W) for p in pts]
+    if world > 1:
+        total_cost = sum(c * k for c, k in zip(chans, cost_pc))
+        cut = total_cost / (8.0 * world) if single_sweep else None  # G = 8: every net within 6 % of balance
+        units = sharding.make_units(chans, cost_pc, max_unit_cost=cut)
+        owner, load = sharding.assign(units, world)
+        if rank == 0 and max(load) > 0:
+            print("==> %d work units over %d ranks, load imbalance %.3f" % (len(units), world, max(load) * world / sum(load)))
+    else:
+        units = sharding.make_units(chans, cost_pc)
+        owner = [0] * len(units)
+    per_layer = {}
+    for u in units:
+        per_layer[u.layer] = per_layer.get(u.layer, 0) + 1
+    mine = [k for k in range(len(units)) if owner[k] == rank]
+    results = {}  # unit index -> (channels of the unit,) fp32
+
     if single_sweep:
         hooks, handles = {}, []
         batch = DeviceBatchAccumulator(dev) if (accumulate == "device" and dev.type == "cuda") else None
-        for i in mine:
-            hooks[i] = _PointHook(pts[i].kind, accumulate, dev, batch=batch, key=i, deferred=deferred)
+        by_layer = {}
+        for k in mine:
+            by_layer.setdefault(units[k].layer, []).append(k)
+        for i, ks in by_layer.items():
+            whole = per_layer[i] == 1
+            hooks[i] = _PointHook(pts[i].kind, accumulate, dev, batch=batch, key=ks[0], deferred=deferred,
+                                  ranges=None if whole else [(k, units[k].c_lo, units[k].c_hi) for k in ks],
+                                  nominal_c=chans[i])
             handles.append(_resolve(net, pts[i].module).register_forward_hook(hooks[i]))
         sweep(net, train_loader, args.limit)
         for h in handles:
             h.remove()
-        for i in mine:
-            results[i] = hooks[i].scores()
+        for i, ks in by_layer.items():
+            for k in ks:
+                results[k] = hooks[i].scores(k)
     else:
-        for i in mine:
+        for k in mine:  # one unit per hook point here
+            i = units[k].layer
             pt = pts[i]
             if args.net == "u2netp" and world == 1:
                 print("current layer:", "net." + pt.module)
             layer = _resolve(net, pt.module)
             if accumulate == "device":
-                hook = _PointHook(pt.kind, accumulate, dev)
+                hook = _PointHook(pt.kind, accumulate, dev, key=k)
                 handler = layer.register_forward_hook(hook)
                 sweep(net, train_loader, args.limit)
                 handler.remove()
-                results[i] = hook.scores()
+                results[k] = hook.scores()
             else:
                 handler = layer.register_forward_hook(_HOOKS[pt.kind])
                 sweep(net, train_loader, args.limit)
                 handler.remove()
-                results[i] = np.ascontiguousarray(_acc.feature_result.numpy(), dtype=np.float32)
+                results[k] = np.ascontiguousarray(_acc.feature_result.numpy(), dtype=np.float32)
                 _acc.reset()
             if world == 1:
-                _save(out_dir, args.net, pt, results[i])
+                _save(out_dir, args.net, pt, results[k])
         if world == 1:
             print("The importance score generation has been completed!")  # utils/common.py:977
             return
 
     if world > 1:
-        results = _gather_results(results, len(pts), owner, world, rank, dev, group)
+        layer_scores = _gather_results(results, units, len(pts), owner, world, rank, dev, group)
+    else:
+        layer_scores = {units[k].layer: results[k] for k in mine}
     if rank == 0:
         for i, pt in enumerate(pts):
             if args.net == "u2netp":
                 print("current layer:", "net." + pt.module)
-            _save(out_dir, args.net, pt, results[i])
+            _save(out_dir, args.net, pt, layer_scores[i])
         print("The importance score generation has been completed!")
     if world > 1:
         torch.distributed.barrier(group)
 
 
-def _gather_results(local, n_layers, owner, world, rank, dev, group):
-    """One all-gather of the flat, equally padded score buffer (plus a tiny all-reduce that
-    tells every rank the channel counts, which only the owners know)."""
+def _gather_results(local, units, n_layers, owner, world, rank, dev, group):
+    """One all-gather of the flat, equally padded score buffer (plus a tiny all-reduce that tells every rank
+    the channel counts of the units, which only their owners know for certain: imp_score also runs on
+    already-pruned nets whose widths differ from the schedule's). Returns {layer: (C,) scores}."""
     import torch.distributed as dist
     backend = dist.get_backend(group)
     cdev = dev if backend == "nccl" else torch.device("cpu")
-    counts = torch.zeros(n_layers, dtype=torch.int64, device=cdev)
-    for i, v in local.items():
-        counts[i] = v.shape[0]
+    counts = torch.zeros(len(units), dtype=torch.int64, device=cdev)
+    for k, v in local.items():
+        counts[k] = v.shape[0]
     dist.all_reduce(counts, group=group)
     counts = counts.cpu().tolist()
-    units = [sharding.Unit(i, 0, c, float(c)) for i, c in enumerate(counts)]
-    off, seg = sharding.layout(units, owner, world)
+    # actual units: a whole hook point spans [0, actual C); a channel range keeps its bounds
+    per_layer = [0] * n_layers
+    for u in units:
+        per_layer[u.layer] += 1
+    real = []
+    for k, u in enumerate(units):
+        if per_layer[u.layer] == 1:
+            real.append(sharding.Unit(u.layer, 0, counts[k], float(counts[k])))
+        else:
+            if counts[k] != u.c_hi - u.c_lo:
+                raise RuntimeError("unit %d of hook point %d came back with %d channels, expected %d"
+                                   % (k, u.layer, counts[k], u.c_hi - u.c_lo))
+            real.append(u)
+    chans = [0] * n_layers
+    for u in real:
+        chans[u.layer] = max(chans[u.layer], u.c_hi)
+    off, seg = sharding.layout(real, owner, world)
     flat = torch.zeros(seg, dtype=torch.float32, device=cdev)
-    for i, v in local.items():
-        flat[off[i]:off[i] + counts[i]] = torch.from_numpy(v).to(cdev)
+    for k, v in local.items():
+        flat[off[k]:off[k] + counts[k]] = torch.from_numpy(v).to(cdev)
     gathered = sharding.all_gather_scores(flat, world, group)
-    res = sharding.unpack(gathered, units, owner, off, counts)
+    res = sharding.unpack(gathered, real, owner, off, chans)
     return {i: r.cpu().numpy() for i, r in enumerate(res)}

@@ -14,10 +14,10 @@ def _workspace(device, stream_ptr, nbytes):
     key = (device.index, stream_ptr)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
-        if buf is not None:
-            _lib.load().dcts_workspace_invalidate(buf.data_ptr())  # the allocator may hand the address out again
+        if buf is not None:  # the allocator may hand these bytes out again
+            _lib.load().dcts_workspace_invalidate_range(buf.data_ptr(), buf.numel())
         buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-        _lib.load().dcts_workspace_invalidate(buf.data_ptr())
+        _lib.load().dcts_workspace_invalidate_range(buf.data_ptr(), buf.numel())
         _workspaces[key] = buf
     return buf
 

@@ -15,6 +15,60 @@ import torch
 Unit = namedtuple("Unit", "layer c_lo c_hi cost")  # channels [c_lo, c_hi) of hook point `layer`
 
 
+def init_process_group(backend, rank=None, world_size=None, device=None, timeout_s=None, what="dct_pruning_amd"):
+    """torch.distributed.init_process_group that cannot hang silently: first contact with RCCL on a new
+    node is where a multi-GPU run dies (IPC mode, a missing link, a rank that never arrives), and a stuck
+    bootstrap would otherwise sit there until the caller's own limit. The rendezvous and every later
+    collective get `timeout_s` (env DCTS_DIST_TIMEOUT_S, default 180); a watchdog thread covers the part
+    of communicator creation that ignores it; one 1-element all-reduce is run and waited for right away
+    so that a broken fabric fails HERE, before any timing. On failure every rank prints one JSON line
+    {"error": ..., "stage": ..., "rank": ...} (rank 0 on stdout, where the drivers read the bench line;
+    the others on stderr) and the process exits with code 3."""
+    import datetime
+    import json
+    import os
+    import sys
+    import threading
+    import torch.distributed as dist
+
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("DCTS_DIST_TIMEOUT_S", "180"))
+    rk = int(os.environ.get("RANK", "0")) if rank is None else rank
+    stage = ["rendezvous"]
+
+    def fail(msg):
+        line = json.dumps({"error": msg, "stage": stage[0], "rank": rk, "backend": backend, "what": what,
+                           "timeout_s": timeout_s})
+        print(line, file=sys.stdout if rk == 0 else sys.stderr, flush=True)
+        if rk == 0:
+            print(line, file=sys.stderr, flush=True)
+        os._exit(3)
+
+    dog = threading.Timer(timeout_s + 15.0, fail, args=("no progress within the time limit (hung bring-up)",))
+    dog.daemon = True
+    dog.start()
+    try:
+        kw = {"timeout": datetime.timedelta(seconds=timeout_s)}
+        if rank is not None:
+            kw.update(rank=rank, world_size=world_size)
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, **kw)
+        stage[0] = "first collective"
+        probe = torch.ones(1, dtype=torch.float32, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)
+        if probe.is_cuda:
+            torch.cuda.synchronize(probe.device)
+        if int(probe.item()) != dist.get_world_size():
+            fail("first all-reduce returned %r, expected %d" % (probe.item(), dist.get_world_size()))
+    except SystemExit:
+        raise
+    except BaseException as exc:  # noqa: BLE001 - whatever it was, it must end the rank loudly
+        fail("%s: %s" % (type(exc).__name__, exc))
+    finally:
+        dog.cancel()
+
+
 def make_units(channel_counts, costs_per_channel, max_unit_cost=None):
     """One unit per layer; layers costlier than max_unit_cost are cut into equal channel ranges."""
     units = []

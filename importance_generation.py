@@ -70,10 +70,9 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            torch.distributed.init_process_group("gloo")
-        else:
-            torch.distributed.init_process_group("nccl", device_id=dev)
+        from dct_pruning_amd import sharding
+        # bounded bring-up: a rank that cannot reach the others prints {"error": ...} and exits 3 (sharding.py)
+        sharding.init_process_group("gloo" if rehearse else "nccl", device=dev, what="importance_generation.py")
 
     torch.manual_seed(args.seed)
     net = nets.get_network(args.net)

@@ -16,8 +16,14 @@
  *
  * Conventions
  *   - All pointers are DEVICE pointers (hipMalloc'd / torch CUDA tensors). The caller owns
- *     every buffer; the library allocates nothing and keeps no state besides immutable
- *     kernel code.
+ *     every buffer; the library allocates no device memory. Its only state, all on the HOST:
+ *       (1) a 16-entry memo of which byte range of which caller workspace holds the direct
+ *           kernel's cosine-basis tables (per workspace pointer, stream and tile shape; see
+ *           dcts_workspace_invalidate - a caller that writes into a workspace or frees it
+ *           must say so);
+ *       (2) values read ONCE per process: the device's CU count and per-kernel occupancy, and
+ *           the environment variable DCTS_SPLIT_CHUNK_MB (size of the two-launch split path's
+ *           intermediate buffer, default 256).
  *   - Strides are in ELEMENTS (floats), as torch.Tensor.stride() reports them.
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Every entry
  *     point only ENQUEUES work on that stream; there is no implicit synchronisation.
@@ -35,7 +41,9 @@
 extern "C" {
 #endif
 
-#define DCTS_ABI_VERSION 1
+/* 2: workspace contract (the library may leave basis tables in a workspace between calls; 16-byte
+ *    alignment; dcts_workspace_invalidate[_range]), multi / mixed / weighted entry points. */
+#define DCTS_ABI_VERSION 2
 
 enum {
   DCTS_OK = 0,
@@ -117,6 +125,9 @@ int dcts_energy_f32_ex(const float* x, int64_t N, int64_t C_total, int64_t H, in
  * workspace, stream and tile shape; remembered on the host, nothing is read back). A caller that writes into a
  * workspace itself, or frees it and allocates another at the same address, says so here first. */
 void dcts_workspace_invalidate(void* workspace);
+/* The same for callers that wrote into (or are about to free) bytes [workspace, workspace + bytes): also
+ * forgets tables cached under other pointers that overlap the range. */
+void dcts_workspace_invalidate_range(void* workspace, size_t bytes);
 
 /* 1 if DCTS_ALGO_CODELET has a kernel for an (H, W) tile (sizes AFTER the odd pad). */
 int dcts_has_codelet(int64_t H, int64_t W);

@@ -45,3 +45,16 @@ def test_bench_u2netp_at_320():
     r = run_bench("--net", "u2netp", "--input-size", "320", "--batch", "2", "--steps", "3", "--warmup", "1",
                   "--no-cpu-baseline", "--no-headline")
     assert "320x320" in r["config"]["workload"] and r["roofline"]["kernel"].startswith("k_split_fused2")
+
+
+def test_bench_rehearsal_with_four_ranks_and_channel_range_units():
+    """`bench.py --gpus N` beyond two ranks. A one-GPU box admits at most six processes on its
+    card, so the eight-rank case is rehearsed over gloo on the CPU (tests/test_distributed_cpu.py) and the
+    bench itself with FOUR ranks here: VGG-16-bn has 12 hook points (< 4 per rank), so the units are channel
+    ranges (bench.py cuts wide layers exactly then) and the sharded result must still pass the device-side
+    Parseval check on every rank's share."""
+    r = run_bench("--gpus", "4", "--net", "vgg_16_bn", "--batch", "32", "--steps", "5", "--warmup", "2",
+                  "--no-cpu-baseline", "--no-headline", rehearse=True)
+    assert r["n_gpus"] == 4 and r["scaling"] == "strong" and "all_gather_ms" in r
+    assert r["parity_check_rel_err"] <= 1e-4 and r["dead_channels_not_plus_zero"] == 0
+    assert r["config"]["load_imbalance"] <= 1.10

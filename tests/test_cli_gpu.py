@@ -100,3 +100,28 @@ def test_two_rank_cli_equals_single_rank(tmp_path):
     for f in os.listdir(d1):
         a, b = np.load(d1 / f), np.load(d2 / f)
         np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * float(a.max()), err_msg=f)
+
+
+def test_four_rank_single_sweep_cli_with_channel_range_units(tmp_path):
+    """The single-sweep modes shard CHANNEL RANGES of wide hook points (VGG-16-bn: 12 hook points, four ranks):
+    rank 0 writes the same 12 files as a single-rank run, every channel exactly once."""
+    common = ["--net", "vgg_16_bn", "--dataset", "cifar10", "--synthetic", "--pretrain_dir", "", "--batch_size", "16",
+              "--limit", "2", "--deferred"]
+    (tmp_path / "one").mkdir()
+    (tmp_path / "four").mkdir()
+    run_cli(tmp_path / "one", *common)
+    env = dict(os.environ, PYTHONPATH=ROOT, DCTS_REHEARSE="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "importance_generation.py"), *common],
+                       cwd=tmp_path / "four", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout
+    assert "work units over 4 ranks" in p.stdout
+    d1 = tmp_path / "one" / "importance_score" / "vgg_16_bn_limit2"
+    d4 = tmp_path / "four" / "importance_score" / "vgg_16_bn_limit2"
+    assert sorted(os.listdir(d1)) == sorted(os.listdir(d4)) and len(os.listdir(d4)) == 12
+    for f in os.listdir(d1):
+        a, b = np.load(d1 / f), np.load(d4 / f)
+        assert a.shape == b.shape
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-6 * float(a.max()), err_msg=f)

@@ -34,22 +34,22 @@ def test_lpt_assignment_and_layout():
     assert g.shape == (1, 4)
 
 
-def _worker(rank, world, port, name, out_root):
+def _worker(rank, world, port, name, out_root, kw=None):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    sharding.init_process_group("gloo", rank=rank, world_size=world, timeout_s=120)  # the product's bounded bring-up
+    torch.set_num_threads(2)  # CPU convolutions round differently at other thread counts; the single-process run uses 2 as well
     from dct_pruning_amd import harness
     from oracle import dct_oracle as orc
     from test_harness_cpu import run_harness
     harness._energy_nc = orc.energy_nc_batched
     d = os.path.join(out_root, "rank%d" % rank)
     os.makedirs(d)
-    run_harness(name, d)
+    run_harness(name, d, **(kw or {}))
     torch.distributed.destroy_process_group()
 
 
@@ -71,3 +71,74 @@ def test_two_rank_gloo_equals_single_process(name, tmp_path, monkeypatch):
         assert got[k].tobytes() == single[k].tobytes(), k
     # only rank 0 writes
     assert not (tmp_path / "rank1" / "importance_score").exists()
+
+
+def _files(root, name):
+    from helpers import HARNESS_CASES
+    d0 = root / "rank0" / "importance_score" / ("%s_limit%d" % (name, HARNESS_CASES[name][1]))
+    return {f[:-4]: np.load(d0 / f) for f in os.listdir(d0)}
+
+
+@pytest.mark.parametrize("name,world,kw", [
+    ("vgg_16_bn", 4, {}),                       # 12 hook points: fewer than 4 per rank
+    ("googlenet", 8, {}),                       # 10 hook points on 8 ranks: two ranks own two
+    ("vgg_16_bn", 8, {"single_sweep": True}),   # channel-range units: 12 hook points cut into >= 32 units
+    ("densenet_40", 4, {"single_sweep": True}),  # last-12-channel hook points next to full ones
+])
+def test_world_4_and_8_gloo_equal_single_process(name, world, kw, tmp_path, monkeypatch):
+    """the sharded harness at world 4 and 8 (gloo), including nets with fewer hook points than
+    4 x ranks and the single-sweep mode whose work units are channel ranges: rank 0's files equal the
+    single-process files byte for byte, and only rank 0 writes."""
+    from dct_pruning_amd import harness
+    from oracle import dct_oracle as orc
+    from test_harness_cpu import run_harness
+    monkeypatch.setattr(harness, "_energy_nc", orc.energy_nc_batched)
+    before = torch.get_num_threads()
+    torch.set_num_threads(2)  # as the workers: the comparison is about the sharding, not about MKL's thread split
+    try:
+        single, _, _ = run_harness(name, tmp_path / "single", **kw)
+    finally:
+        torch.set_num_threads(before)
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, name, str(tmp_path), kw), nprocs=world, join=True)
+    got = _files(tmp_path, name)
+    assert sorted(got) == sorted(single)
+    for k in single:
+        assert got[k].tobytes() == single[k].tobytes(), k
+    for r in range(1, world):
+        assert not (tmp_path / ("rank%d" % r) / "importance_score").exists()
+
+
+def test_channel_range_units_balance_eight_ranks():
+    """What imp_score's single-sweep modes hand to LPT at G = 8: every net within 6 % of perfect balance,
+    although VGG-16-bn / GoogLeNet have only 12 / 10 hook points (whole-layer units: 1.5-2.3 x)."""
+    from dct_pruning_amd import schedules
+    for name, fn in schedules.SCHEDULES.items():
+        pts = fn()
+        chans = [schedules.scored_shape(p)[1] for p in pts]
+        cpc = [float(p.H * p.W) for p in pts]
+        total = sum(c * k for c, k in zip(chans, cpc))
+        units = sharding.make_units(chans, cpc, max_unit_cost=total / 64.0)  # imp_score: total / (8 * world)
+        _, load = sharding.assign(units, 8)
+        assert max(load) * 8 / total <= 1.06, (name, max(load) * 8 / total)
+        covered = sum(u.c_hi - u.c_lo for u in units)
+        assert covered == sum(chans)
+
+
+def _failing_worker(rank, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    # rank 1 of 2 never arrives: the bring-up must end this rank with code 3 and a JSON line, not hang
+    sharding.init_process_group("gloo", rank=0, world_size=2, timeout_s=5, what="test")
+
+
+def test_bring_up_that_cannot_complete_exits_loudly(capfd):
+    import multiprocessing
+    ctx = multiprocessing.get_context("spawn")
+    p = ctx.Process(target=_failing_worker, args=(0, 33500 + (os.getpid() % 2000)))
+    p.start()
+    p.join(60)
+    assert not p.is_alive(), "bring-up hung"
+    assert p.exitcode == 3
+    out = capfd.readouterr()
+    assert '"error"' in out.out and '"stage": "rendezvous"' in out.out

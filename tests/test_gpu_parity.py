@@ -412,3 +412,58 @@ def test_direct_kernel_basis_tables_are_cached_safely():
     got = dpa.dct2d(x.cuda(), algo=dpa.ALGO_DIRECT).cpu().numpy()
     assert np.abs(got - orc.dct_2d_f64(x.numpy())).max() <= 2e-6 * np.abs(got).max()
     check((24, 24))
+
+
+def test_weighted_calls_of_several_shapes_share_one_workspace_safely():
+    """the weighted path hands the coefficient path an INTERIOR pointer of the workspace whose offset
+    depends on the tile shape; tables cached under such pointers were never dropped. Weighted 24x24, weighted
+    12x12 (its tables land inside the 24x24 ones), weighted 24x24 again, then a large direct energy call - all on
+    the ONE workspace ops.py keeps per (device, stream) - must each give the float64 definition."""
+    from dct_pruning_amd import ops
+
+    def weighted(n, seed):
+        x = synth(2, 5, n, n, seed, dead=False)
+        g = torch.Generator().manual_seed(seed + 1)
+        w = torch.rand(n, n, generator=g)
+        got = dpa.weighted_energy_nc(x.cuda(), w.cuda()).cpu()
+        ref = torch.from_numpy(orc.weighted_energy_nc_f64(x, w.numpy()))
+        assert rel_err(got, ref) <= 2e-5, n
+
+    # size the shared workspace once, generously, so that every call below reuses the same buffer
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    base = ops._workspace(dev, stream, 64 << 20).data_ptr()
+    weighted(24, 1)
+    weighted(12, 2)
+    weighted(24, 3)
+    x = synth(2, 64, 24, 24, 4)
+    check(x, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT))
+    weighted(30, 5)
+    check(x, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT))  # its tables were overwritten by the weighted call
+    x2 = synth(1, 600, 30, 20, 6)  # many maps: the T tiles reach far into the workspace
+    got = dpa.energy_nc(x2.cuda(), algo=dpa.ALGO_DIRECT).cpu()
+    assert rel_err(got, orc.energy_nc(x2)) <= RTOL
+    weighted(12, 7)
+    assert ops._workspace(dev, stream, 1).data_ptr() == base  # one buffer throughout
+
+
+@pytest.mark.parametrize("n", [72, 288])
+def test_large_tile_with_a_4_byte_aligned_base(n):
+    """Every split-family kernel stages with 16-byte direct-to-LDS loads; a view whose base is only 4-byte
+    aligned takes the direct kernel under AUTO and is refused by an explicit large-tile family."""
+    from dct_pruning_amd._lib import DctScoreError
+    c = 3
+    x = synth(1, c, n, n, 700 + n)
+    flat = torch.zeros(c * n * n + 1)
+    flat[1:] = x.reshape(-1)
+    view = flat.cuda()[1:].view(1, c, n, n)
+    assert view.data_ptr() % 16 == 4
+    got = dpa.energy_nc(view).cpu()
+    ref = torch.from_numpy(orc.energy_nc_f64(x)).float()
+    assert rel_err(got, ref) <= RTOL
+    for algo in (dpa.ALGO_FUSED, dpa.ALGO_SPLIT):
+        with pytest.raises(DctScoreError) as ei:
+            dpa.energy_nc(view, algo=algo)
+        assert ei.value.code == -6  # DCTS_E_UNSUPPORTED
+    # the aligned tensor itself goes through the large-tile kernel and agrees
+    assert rel_err(dpa.energy_nc(x.cuda()).cpu(), got) <= 1e-5
