@@ -59,6 +59,10 @@ int dispatch_tile2d(int N, const void* tile_batch, hipStream_t st);  // tile2d.h
 int dispatch_fused_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
 int dispatch_fused2_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
 int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
+// tile2g.hip: mid-size edges as a 2-D radix split with several maps per round
+int has_tile2g(int N);
+int dispatch_tile2g(int N, const void* tile_batch, hipStream_t st);
+int dispatch_tile2g_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
 }  // namespace dctsi
 
 namespace {
@@ -2424,13 +2428,25 @@ bool has_codelet(long long HP, long long WP) {
 
 // which single-launch large-tile kernel serves an edge: 0 none, 1 fused, 2 fused with two roles per
 // wave, 3 pipelined (AUTO order: pipelined, two-roles, fused)
-bool has_tile2d(long long N) { return N == 224; }
+bool has_tile2d(long long N) { return N == 224 || dctsi::has_tile2g((int)N) != 0; }
 
-int tile_family(int HP, int algo) {
-  if (algo == DCTS_ALGO_TILE2D) return has_tile2d(HP) ? 4 : 0;
+// Does AUTO take the several-maps-per-round 2-D split (tile2g.hip, family 5) for `nmaps` maps of edge HP? Same box,
+// % of the HBM peak, fused / pipelined kernel -> tile2g: 72: 30.9 -> 44.1 (9645 maps), 29.7 -> 45.1 (32768); 80: 33.2 ->
+// 40.3, 32.9 -> 37.6; 144: 30.1 -> 33.7 (2411), 32.0 -> 42.4 (4992), 31.8 -> 41.0 (8192); 160: 31.2 -> 34.1 (1953), 33.5 ->
+// 37.3 (4096); 128: 45.1 -> 43.3 (3051) but 44.1 -> 50.6 (8192); 112: 38.8 -> 34.6, 39.8 -> 38.2
+// (profiles/r03_tile2g_vs_fused_same_box.txt). The choice must not depend on the map count: dcts_energy_multi_f32
+// promises the bits of one call per tensor, whatever the tensors' sizes. So 72, 80, 144, 160 take it, 112 and 128
+// keep the fused / pipelined kernels (DCTS_ALGO_TILE2D still selects it for them).
+bool tile2g_auto(int HP, long long /*nmaps*/) {
+  return dctsi::has_tile2g(HP) && HP != 112 && HP != 128;
+}
+
+int tile_family(int HP, int algo, long long nmaps) {
+  if (algo == DCTS_ALGO_TILE2D) return HP == 224 ? 4 : (dctsi::has_tile2g(HP) ? 5 : 0);
+  if (algo == DCTS_ALGO_AUTO && tile2g_auto(HP, nmaps)) return 5;
   // AUTO order: 2-D split (tile2d.hip), pipelined, two-roles, fused. 224: 2-D split 33-42 % of the HBM
   // peak against 31-37 % pipelined, same box, 996...16384 maps
-  if (algo == DCTS_ALGO_AUTO && has_tile2d(HP)) return 4;
+  if (algo == DCTS_ALGO_AUTO && HP == 224) return 4;
   if (algo == DCTS_ALGO_PIPE) return has_pipe(HP) && has_fused(HP) ? 3 : 0;
   if (algo == DCTS_ALGO_AUTO && has_pipe(HP) && has_fused(HP)) return 3;
   if (has_fused2(HP) && (algo == DCTS_ALGO_FUSED || DCTS_FUSED2_AUTO)) return 2;
@@ -2439,6 +2455,8 @@ int tile_family(int HP, int algo) {
 }
 int dispatch_tile_family(int fam, int HP, const TileBatch& tb, hipStream_t st) {
   switch (fam) {
+    case 5:
+      return dctsi::dispatch_tile2g(HP, &tb, st);
     case 4:
       return dctsi::dispatch_tile2d(HP, &tb, st);
     case 3:
@@ -2569,7 +2587,7 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
                           strideC == H * W && aligned16;
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
     if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) {
-      const int fam = (split_ok && aligned16) ? tile_family((int)HP, algo) : 0;
+      const int fam = (split_ok && aligned16) ? tile_family((int)HP, algo, g.nmaps) : 0;
       if (fam) {
         TileBatch tb;
         for (int i = 0; i < kTileItems; ++i) {
@@ -2606,7 +2624,9 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
       const float* x0 = x + (long long)c_begin * strideC;
       float* scratch = reinterpret_cast<float*>(workspace);
       basis_forget_range(workspace, workspace_bytes);
-      if (algo == DCTS_ALGO_TILE2D) return dctsi::dispatch_tile2d_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
+      if (algo == DCTS_ALGO_TILE2D)
+        return HP == 224 ? dctsi::dispatch_tile2d_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st)
+                         : dctsi::dispatch_tile2g_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
       if (has_fused2(HP)) return dctsi::dispatch_fused2_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
       return dctsi::dispatch_fused_coeff((int)HP, x0, g.nmaps, out, scratch, ws_maps, st);
     }
@@ -2842,7 +2862,7 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
   // large tiles with a single-launch kernel: the dense tensors go into ONE launch per 32 of them (their
   // maps form one index space: a CU that would get a fraction of a map from one small tensor now
   // draws from all of them); results are those of one call per tensor, bit for bit
-  const int fam = (pad == 0 && H == W && has_split(HP, WP)) ? tile_family((int)HP, DCTS_ALGO_AUTO) : 0;
+  const int fam = (pad == 0 && H == W && has_split(HP, WP)) ? tile_family((int)HP, DCTS_ALGO_AUTO, 0) : 0;
   TileBatch tb;
   int nb = 0;
   auto flush = [&]() -> int {

@@ -882,14 +882,19 @@ __global__ __launch_bounds__(64 * kT2Waves) void k_tile2d(TileBatch tb, float* l
 
 #define DCTS_TILE2D_TABLE(X) X(224, 28)
 
-template <int M>
-int launch_tile2d(const TileBatch& tb, hipStream_t st) {
+int t2_num_cus() {
   static const int ncu = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
       n = 256;
     return n;
   }();
+  return ncu;
+}
+
+template <int M>
+int launch_tile2d(const TileBatch& tb, hipStream_t st) {
+  const int ncu = t2_num_cus();
   const long long grid = tb.total < ncu ? tb.total : ncu;  // LDS: one workgroup per CU
   hipLaunchKernelGGL((k_tile2d<M, false>), dim3((unsigned)grid), dim3(64 * kT2Waves), 0, st, tb, (float*)nullptr);
   return (int)hipGetLastError();
@@ -956,7 +961,7 @@ int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, fl
     tb.map_elems = (long long)N * N;
     tb.total = nb;
     tb.count = 1;
-    const long long grid = nb < 256 ? nb : 256;
+    const long long grid = nb < t2_num_cus() ? nb : t2_num_cus();  // as the energy launch: one persistent workgroup per CU
     hipLaunchKernelGGL((k_tile2d<M, true>), dim3((unsigned)grid), dim3(64 * kT2Waves), 0, st, tb, scratch);
     int rc = (int)hipGetLastError();
     if (rc) return rc;

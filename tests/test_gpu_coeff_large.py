@@ -19,7 +19,8 @@ TOL = 2e-6  # of the coefficient scale (max |coefficient| of the map batch)
 
 @pytest.mark.parametrize("edge,algo", [(72, "FUSED"), (80, "FUSED"), (112, "FUSED"), (128, "FUSED"), (144, "FUSED"),
                                        (160, "FUSED"), (224, "FUSED"), (256, "FUSED"), (288, "FUSED"), (320, "FUSED"),
-                                       (224, "TILE2D")])
+                                       (224, "TILE2D"), (72, "TILE2D"), (80, "TILE2D"), (112, "TILE2D"), (128, "TILE2D"),
+                                       (144, "TILE2D"), (160, "TILE2D")])
 def test_large_tile_coefficients_vs_float64(edge, algo):
     x = synth(1, 3, edge, edge, 400 + edge, dead=False)
     got = dpa.dct2d(x.cuda(), algo=getattr(dpa, "ALGO_" + algo)).cpu().numpy()
@@ -50,12 +51,32 @@ def test_single_basis_function_known_answer_224(algo):
         assert np.abs(got[i] - want).max() <= 5e-6, (u, v)
 
 
+@pytest.mark.parametrize("n", [72, 144])
+def test_single_basis_function_known_answer_tile2g(n):
+    """The same known-answer test for the several-maps-per-round kernel (tile2g.hip), 7 maps = two full rounds and a
+    short one: x = outer(C[u, :], C[v, :]) has exactly one unit coefficient, at (u, v)."""
+    k = np.arange(n)
+    rows = []
+    picks = [(0, 0), (1, 0), (0, n - 1), (5, 17), (n // 2 - 1, n // 2), (n - 1, n - 1), (n // 8, n // 4)]
+    for u, v in picks:
+        cu = np.cos(np.pi * (2 * k + 1) * u / (2 * n)) * (np.sqrt(1.0 / n) if u == 0 else np.sqrt(2.0 / n))
+        cv = np.cos(np.pi * (2 * k + 1) * v / (2 * n)) * (np.sqrt(1.0 / n) if v == 0 else np.sqrt(2.0 / n))
+        rows.append(np.outer(cu, cv))
+    x = torch.from_numpy(np.stack(rows)[None].astype(np.float32))
+    got = dpa.dct2d(x.cuda(), algo=dpa.ALGO_TILE2D).cpu().numpy()[0]
+    for i, (u, v) in enumerate(picks):
+        want = np.zeros((n, n))
+        want[u, v] = 1.0
+        assert np.abs(got[i] - want).max() <= 5e-6, (u, v)
+
+
 def test_chunked_workspace_gives_the_same_coefficients():
     """More maps than the workspace holds tiles: the coefficient path runs in chunks."""
     x = synth(2, 40, 72, 72, 77, dead=False).cuda()
-    a = dpa.dct2d(x, algo=dpa.ALGO_FUSED)
     ref = orc.dct_2d_f64(x.cpu().numpy())
-    assert np.abs(a.cpu().numpy() - ref).max() <= TOL * np.abs(ref).max()
+    for algo in (dpa.ALGO_FUSED, dpa.ALGO_TILE2D):  # tile2g rounds of 3 maps against chunks of whatever the workspace holds
+        a = dpa.dct2d(x, algo=algo)
+        assert np.abs(a.cpu().numpy() - ref).max() <= TOL * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("edge", [8, 9, 32, 56, 72, 224, 288, 24])
