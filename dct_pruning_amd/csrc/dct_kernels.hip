@@ -39,6 +39,9 @@
 #ifndef DCTS_TU
 #define DCTS_TU 0
 #endif
+#ifndef DCTS_F2_EXP
+#define DCTS_F2_EXP 0  // timing experiments on k_split_fused2 (wrong results): 1 no staging loads, 2 no pass-1 butterflies, 3 no pass-2 butterflies, 4 no codelet arithmetic
+#endif
 #ifndef DCTS_FUSED2_AUTO
 #define DCTS_FUSED2_AUTO 1  // AUTO uses the two-roles-per-wave fused kernel where it exists (288: 31 % vs 18 %, 320: 31 % vs 17 % of the HBM peak)
 #endif
@@ -766,10 +769,14 @@ __device__ __forceinline__ void split_role_transform(lds_cptr col, int rs, float
     constexpr int row = (SLOT % 2 == 0) ? SLOT * M + p : SLOT * M + M - 1 - p;
     in[q] = col[row * rs];
   });
+#if DCTS_F2_EXP == 4
+  dcts::static_for<M>([&](auto i) DCTS_LAMBDA_INLINE { out[decltype(i)::value] = in[decltype(i)::value] * 1.5f; });
+#else
   if constexpr (Leaf::is4)
     dcts::Dct4<M>::run(in, out);
   else
     dcts::Dct2<M>::run(in, out);
+#endif
   constexpr float w0 = float(Leaf::wt(true)), w1 = float(Leaf::wt(false));
   if constexpr (w0 != 1.0f) out[0] *= w0;
   if constexpr (w1 != 1.0f)
@@ -1247,19 +1254,25 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
       const bool more = (s + 1 < STRIPS) || (m + gridDim.x < nmaps);
       const float* nsrc = (s + 1 < STRIPS || !more) ? in_b : tile_in(tb, m + gridDim.x);
       constexpr int nstrip = (s + 1 < STRIPS) ? s + 1 : 0;
+#if DCTS_F2_EXP != 1
       if (more) {
 #pragma unroll
         for (int it = 0; it < Stage::PIECES; it += 2) Stage::piece_raw(nsrc, nstrip, nxt, launder(lane_in), W, it);
       }
+#endif
       int lane = launder(lane_in);
       const bool act = s * SW + lane < N;
       DCTS_STAMP(2);
+#if DCTS_F2_EXP != 2
       split_butterflies<M, L, NoHook, false, NW>(buf, SW, act, lane, W);
+#endif
       DCTS_STAMP(3);
+#if DCTS_F2_EXP != 1
       if (more) {
 #pragma unroll
         for (int it = 1; it < Stage::PIECES; it += 2) Stage::piece_raw(nsrc, nstrip, nxt, launder(lane_in), W, it);
       }
+#endif
       DCTS_STAMP(2);
       lds_barrier();
       DCTS_STAMP(4);
@@ -1308,7 +1321,9 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
       DCTS_STAMP(8);
       lane = launder(lane_in);
       const bool colact = lane < COLS;
+#if DCTS_F2_EXP != 3
       split_butterflies<M, L, NoHook, false, NW>(blk, RW, colact, lane, W);
+#endif
       DCTS_STAMP(9);
       lds_barrier();
       DCTS_STAMP(10);
@@ -2017,8 +2032,8 @@ inline int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* ou
 // where the four-role codelets would be too register-hungry for more than 1-2 waves per SIMD.
 #ifndef DCTS_SPLIT_TABLE
 #define DCTS_SPLIT_TABLE(X)                                                              \
-  X(72, 18, 2) X(80, 20, 2) X(112, 28, 2) X(128, 32, 2) X(144, 36, 2) X(160, 40, 2)      \
-  X(224, 28, 3) X(256, 32, 3) X(288, 36, 3) X(320, 40, 3)
+  X(72, 18, 2) X(80, 20, 2) X(96, 24, 2) X(112, 28, 2) X(128, 32, 2) X(144, 36, 2) X(160, 40, 2)      \
+  X(192, 24, 3) X(224, 28, 3) X(256, 32, 3) X(288, 36, 3) X(320, 40, 3)
 #endif
 
 bool has_split(long long HP, long long WP) {
@@ -2094,7 +2109,8 @@ int launch_split(const MapGeom& g, float* out, void* workspace, hipStream_t st) 
 // 128: 16x8 38 %, 32x4 35 %, 8x16 22 %; 288 = 18x16 spills at 128 VGPRs and loses to two launches)
 #ifndef DCTS_FUSED_TABLE
 #define DCTS_FUSED_TABLE(X) \
-  X(72, 9, 3) X(80, 10, 3) X(112, 14, 3) X(128, 16, 3) X(144, 18, 3) X(160, 10, 4) X(224, 14, 4) X(256, 16, 4)
+  X(72, 9, 3) X(80, 10, 3) X(96, 12, 3) X(112, 14, 3) X(128, 16, 3) X(144, 18, 3) X(160, 10, 4) X(192, 12, 4) X(224, 14, 4) \
+  X(256, 16, 4)
 #endif
 
 bool has_fused(long long N) {

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 from scipy.fft import dct, dctn
 
-SIZES = [2, 4, 7, 8, 9, 10, 14, 16, 18, 20, 28, 32, 36, 40, 48, 56, 64]
+SIZES = [2, 4, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24, 28, 30, 32, 36, 40, 48, 56, 60, 64]
 FP = ctypes.POINTER(ctypes.c_float)
 
 

@@ -11,7 +11,7 @@ from oracle import dct_oracle as orc
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
-EDGES = [2, 4, 7, 8, 9, 10, 14, 16, 18, 20, 28, 32, 36, 40, 48, 56, 64, 72, 80, 112, 128, 144, 160, 224, 256]
+EDGES = [2, 4, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24, 28, 30, 32, 36, 40, 48, 56, 60, 64, 72, 80, 96, 112, 128, 144, 160, 192, 224, 256]
 
 
 def _rel(got, ref):

@@ -11,8 +11,8 @@ from oracle import dct_oracle as orc
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4
-CODELET = [2, 4, 7, 8, 9, 10, 14, 16, 18, 20, 28, 32, 36, 40, 48, 56, 64]
-DIRECT_ONLY = [3, 5, 12, 24, 72, 80, 144, 224]
+CODELET = [2, 4, 6, 7, 8, 9, 10, 12, 14, 16, 18, 20, 24, 28, 30, 32, 36, 40, 48, 56, 60, 64]
+DIRECT_ONLY = [3, 5, 13, 22, 72, 80, 144, 224]
 
 
 def synth(n, c, h, w, seed, dead=True):
@@ -70,8 +70,8 @@ def test_direct_sizes(n):
     check(x, got)
 
 
-SPLIT = [72, 80, 112, 128, 144, 160, 224, 256, 288, 320]
-FUSED = [72, 80, 112, 128, 144, 160, 224, 256, 288, 320]
+SPLIT = [72, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320]
+FUSED = [72, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320]
 TILE2G = [72, 80, 112, 128, 144, 160]   # tile2g.hip: several maps per round (DCTS_ALGO_TILE2D selects it for these edges)
 TILE2G_AUTO = [72, 80, 144, 160]        # ... and AUTO takes it for these
 
@@ -464,8 +464,8 @@ def test_direct_kernel_basis_tables_are_cached_safely():
 
 def test_weighted_calls_of_several_shapes_share_one_workspace_safely():
     """the weighted path hands the coefficient path an INTERIOR pointer of the workspace whose offset
-    depends on the tile shape; tables cached under such pointers were never dropped. Weighted 24x24, weighted
-    12x12 (its tables land inside the 24x24 ones), weighted 24x24 again, then a large direct energy call - all on
+    depends on the tile shape; tables cached under such pointers were never dropped. Weighted 22x22, weighted
+    13x13 (its tables land inside the 22x22 ones), weighted 22x22 again, then a large direct energy call - all on
     the ONE workspace ops.py keeps per (device, stream) - must each give the float64 definition."""
     from dct_pruning_amd import ops
 
@@ -481,17 +481,18 @@ def test_weighted_calls_of_several_shapes_share_one_workspace_safely():
     dev = torch.device("cuda:0")
     stream = torch.cuda.current_stream(dev).cuda_stream
     base = ops._workspace(dev, stream, 64 << 20).data_ptr()
-    weighted(24, 1)
-    weighted(12, 2)
-    weighted(24, 3)
-    x = synth(2, 64, 24, 24, 4)
+    assert not dpa.has_codelet(22, 22) and not dpa.has_codelet(13, 13) and not dpa.has_codelet(26, 26)  # direct kernel
+    weighted(22, 1)
+    weighted(13, 2)
+    weighted(22, 3)
+    x = synth(2, 64, 22, 22, 4)
     check(x, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT))
-    weighted(30, 5)
+    weighted(26, 5)
     check(x, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT))  # its tables were overwritten by the weighted call
     x2 = synth(1, 600, 30, 20, 6)  # many maps: the T tiles reach far into the workspace
     got = dpa.energy_nc(x2.cuda(), algo=dpa.ALGO_DIRECT).cpu()
     assert rel_err(got, orc.energy_nc(x2)) <= RTOL
-    weighted(12, 7)
+    weighted(13, 7)
     assert ops._workspace(dev, stream, 1).data_ptr() == base  # one buffer throughout
 
 
