@@ -47,6 +47,13 @@ int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, fl
 
 namespace {
 
+// Instruction-mix replay (tools/t2_dev.py on a -DDCTS_T2_EXP=3 build): the product kernel with every
+// instruction in place but NO memory traffic - the loads of the next map read a zero-length buffer (the hardware
+// returns 0 without a request) and the direct-to-LDS pieces are not issued. What it measures is the ceiling of the
+// CU-side work of this design: cycles per map at 16 waves if HBM cost nothing (results are wrong by construction).
+#ifndef DCTS_T2_EXP
+#define DCTS_T2_EXP 0
+#endif
 constexpr int kT2L = 3, kT2S = 8, kT2Waves = 16;
 constexpr RolePlan<kT2L> kT2Plan{};
 
@@ -106,8 +113,13 @@ constexpr int t2_set_slot(int set, int i, int bmax) {
   int role_of_slot[kT2S] = {};
   for (int r = 0; r < kT2S; ++r) role_of_slot[kT2Plan.slot_of_role[r]] = r;
   int n = 0;
+#ifdef DCTS_T2_AMAJOR
+  for (int a = 0; a < kT2S; ++a)
+    for (int b = 0; b < bmax; ++b)
+#else
   for (int b = 0; b < bmax; ++b)
     for (int a = 0; a < kT2S; ++a)
+#endif
       if (kT2Sch.set_of[role_of_slot[a] * kT2S + role_of_slot[b]] == set) {
         if (n == i) return a * kT2S + b;
         ++n;
@@ -601,7 +613,7 @@ template <int M, int B0, int B1>
 __device__ __forceinline__ void t2_load(const float* __restrict__ in_b, int p, int q, float (&v)[kT2S][kT2S]) {
   constexpr int N = T2Cfg<M>::N;
   const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, N * N * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, DCTS_T2_EXP == 3 ? 0 : N * N * 4, 0x00020000);
   const int pe = p, po = M - 1 - p, qe = q, qo = M - 1 - q;
   const int o_ee = (pe * N + qe) * 4, o_eo = (pe * N + qo) * 4, o_oe = (po * N + qe) * 4, o_oo = (po * N + qo) * 4;
   dcts::static_for<kT2S>([&](auto ia) DCTS_LAMBDA_INLINE {
@@ -619,7 +631,7 @@ template <int M, int I0, int I1>
 __device__ __forceinline__ void t2_load_seq(const float* __restrict__ in_b, int p, int q, float (&v)[kT2S][kT2S]) {
   constexpr int N = T2Cfg<M>::N;
   const __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, N * N * 4, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in_b), 0, DCTS_T2_EXP == 3 ? 0 : N * N * 4, 0x00020000);
   const int pe = p, po = M - 1 - p, qe = q, qo = M - 1 - q;
   const int o_ee = (pe * N + qe) * 4, o_eo = (pe * N + qo) * 4, o_oe = (po * N + qe) * 4, o_oo = (po * N + qo) * 4;
   dcts::static_for<(I1 > I0 ? I1 - I0 : 0)>([&](auto ii) DCTS_LAMBDA_INLINE {
@@ -822,7 +834,8 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
           // the raw image is free since barrier #1 (phase A has read it): the next map's pieces, one
           // per wave and hook point (49 for 224x224; the 16 waves issue 16 at a time)
           constexpr int kk = decltype(k)::value;
-          for (int i = wave + kT2Waves * kk; i < Cfg::RAW_PIECES; i += 3 * kT2Waves) t2_dma_piece<M>(nsrc, raw, i, launder(lane_in));
+          if (DCTS_T2_EXP != 3)
+            for (int i = wave + kT2Waves * kk; i < Cfg::RAW_PIECES; i += 3 * kT2Waves) t2_dma_piece<M>(nsrc, raw, i, launder(lane_in));
         }
         if constexpr (n > 0) {
           int p, q;
