@@ -170,6 +170,17 @@ def cpu_baseline(points, seconds):
     }
 
 
+def lib_sha256():
+    """Content hash of the library this process runs (stamps profiles/pmc_traffic_bench.json)."""
+    import hashlib
+    from dct_pruning_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def kernel_name(edge, per_tensor):
     """The kernel dcts_energy_f32 / dcts_energy_multi_f32 (AUTO) runs for a square tile edge."""
     if edge in (7, 9):
@@ -182,7 +193,9 @@ def kernel_name(edge, per_tensor):
         return "k_split_pipe (%dx%d)" % (edge, edge)
     if edge in (288, 320):
         return "k_split_fused2 (%dx%d)" % (edge, edge)
-    if edge in (72, 80, 112, 144, 160, 256):
+    if edge in (72, 80, 144, 160):
+        return "k_tile2g (%dx%d)" % (edge, edge)
+    if edge in (96, 112, 192, 256):
         return "k_split_fused (%dx%d)" % (edge, edge)
     return "k_energy_direct (%dx%d)" % (edge, edge)
 
@@ -498,18 +511,30 @@ def main():
         # corrected by the known-size calibration read of the same run); null when the record is for another
         # workload / launch size
         traffic = None
+        traffic_note = "no PMC record (profiles/pmc_traffic_bench.json)"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic_bench.json")
         alg_per_launch = dom_bytes / n_launch
         if os.path.isfile(tpath):
             try:
+                # the record is only valid for the binary it was measured on: it carries the SHA-256 of libdctscore.so
+                # (the build is reproducible: the same sources give the same bytes on any box of this image)
+                stamp = json.load(open(tpath)).get("libdctscore_sha256")
+                mine = lib_sha256()
+                if stamp != mine:
+                    raise ValueError("PMC record is for another build of libdctscore.so (%s..., this one %s...)"
+                                     % (str(stamp)[:12], mine[:12]))
                 want = ("k_energy_codelet_mixed" if mixed is not None else kernel_name(dom_edge, args.per_tensor)).split(" ")[0].split("<")[0]
                 for kname, rec in json.load(open(tpath)).get("kernels", {}).items():
                     if kname.split("<")[0] == want and rec.get("alg_bytes_per_launch") and \
                             abs(rec["alg_bytes_per_launch"] - alg_per_launch) <= 0.01 * alg_per_launch:
                         if mixed is not None or ("<%d, %d" % (dom_edge, dom_edge)) in kname or "tile2d" in kname or "split" in kname:
                             traffic = rec["hbm_bytes_per_launch"]
-            except Exception:
+                            traffic_note = "PMC passes of this bench at this launch size on this binary (sha256 %s...)" % mine[:12]
+                if traffic is None:
+                    traffic_note = "PMC record is for another workload or launch size"
+            except Exception as exc:
                 traffic = None
+                traffic_note = str(exc)
         res = {
             "metric": "feature-map DCT+score throughput", "value": maps_per_step * args.steps / dt / 1e6,
             "unit": "Mmaps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -526,7 +551,7 @@ def main():
             "roofline": {"bound": "hbm",
                          "kernel": "k_energy_codelet_mixed (edges 2..32)" if mixed is not None else kernel_name(dom_edge, args.per_tensor),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "launches": n_launch, "timed_steps": timed_steps, "avg_launch_us": dom_ms / n_launch * 1e3,
                          "alg_bytes_per_launch": dom_bytes / n_launch},
             "parity_check_rel_err": rel, "dead_channels_not_plus_zero": dead_bad,

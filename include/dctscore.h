@@ -68,12 +68,13 @@ enum {
   DCTS_ALGO_PREFETCH = 4, /* codelet kernel with direct-to-LDS prefetch of the next maps (dense,
                              even-edge square tiles; measured equal to ALGO_CODELET, opt-in)     */
   DCTS_ALGO_FUSED = 5,    /* single-launch split kernel, intermediate tile parked in VGPRs
-                             (edges 72 ... 256; 288 and 320 with two roles per wave)             */
+                             (edges 72 ... 256 incl. 96 and 192; 288 and 320 with two roles per wave) */
   DCTS_ALGO_PIPE = 6,     /* the fused kernel software-pipelined: pass 2 of one map interleaved
                              with pass 1 of the next                                             */
   DCTS_ALGO_LANE = 7,     /* one lane per map, both passes in registers (7x7, 9x9)              */
-  DCTS_ALGO_TILE2D = 8    /* edge 8*M: radix-8 butterflies over both axes in registers, then 64
-                             independent M x M leaf blocks (tile2d.hip)                          */
+  DCTS_ALGO_TILE2D = 8    /* 2-D radix split: butterflies over both axes in registers, then 4^L independent
+                             M x M leaf blocks - 224 (tile2d.hip); 72, 80, 112, 128, 144, 160 with several maps
+                             per round (tile2g.hip)                                              */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */
