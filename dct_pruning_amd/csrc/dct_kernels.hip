@@ -974,14 +974,14 @@ __device__ unsigned long long g_fused_stamps[16][16];
 
 // sum of a map's per-wave partials in fixed order (wave 0, lane 0) and the final scale
 template <int M, int L, int ROLE, class Src>
-__device__ __forceinline__ void fused_finish(lds_ptr partials, int slot, long long m, const Src& tb, int lane) {
+__device__ __forceinline__ void fused_finish(lds_ptr partials, int slot, long long m, const Src& tb, int lane, int* hint = nullptr) {
   constexpr int S = 1 << L, N = M << L;
   if (ROLE == 0 && lane == 0) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < S; ++i) t += partials[slot * S + i];
     constexpr float sc = float(4.0 / (double(N) * double(N)));
-    *tile_out(tb, m) = t * sc;
+    *tile_out(tb, m, hint) = t * sc;
   }
 }
 
@@ -1002,13 +1002,14 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
   const long long nmaps = tb.total;
+  int hint_in = 0, hint_next = 0, hint_out = 0;  // tensor of the current / next / finished map (tile_item)
   if (m < nmaps) {
     const float* first = tile_in(tb, m);
 #pragma unroll
     for (int it = 0; it < FusedStage<M, L>::PIECES; ++it) FusedStage<M, L>::piece_raw(first, 0, lds, lane, ROLE, it);
   }
   for (; m < nmaps; m += gridDim.x) {
-    const float* in_b = tile_in(tb, m);
+    const float* in_b = tile_in(tb, m, &hint_in);
     float parked[STRIPS][M];
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
@@ -1019,7 +1020,7 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
       lds_barrier();                                   // ... for everyone; the other buffer is free
       if constexpr (s == 0) {
         if (pending_m >= 0) {
-          if constexpr (!STORE) fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
+          if constexpr (!STORE) fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane, &hint_out);
           pending_m = -1;
         }
       }
@@ -1029,7 +1030,7 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
       // the next strip (or the next map's first one) streams into the other buffer while this one
       // is transformed; its load instructions are trickled out between the butterflies
       const bool more = (s + 1 < STRIPS) || (m + gridDim.x < nmaps);
-      const float* nsrc = (s + 1 < STRIPS || !more) ? in_b : tile_in(tb, m + gridDim.x);
+      const float* nsrc = (s + 1 < STRIPS || !more) ? in_b : tile_in(tb, m + gridDim.x, &hint_next);
       constexpr int nstrip = (s + 1 < STRIPS) ? s + 1 : 0;
       int piece = more ? 0 : FusedStage<M, L>::PIECES;
       auto trickle = [&]() DCTS_LAMBDA_INLINE {
@@ -1129,7 +1130,7 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
   }
   if (pending_m >= 0) {
     lds_barrier();
-    if constexpr (!STORE) fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane);
+    if constexpr (!STORE) fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane, &hint_out);
   }
 #ifdef DCTS_FUSED_STAMPS
   if (lane == 0)
@@ -1218,13 +1219,14 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
   unsigned long long acc_[16] = {}, last_;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
 #endif
+  int hint_in = 0, hint_next = 0, hint_out = 0;  // tensor of the current / next / finished map (tile_item)
   auto finish = [&](lds_ptr part, int slot, long long mm) DCTS_LAMBDA_INLINE {
     if (W == 0 && lane_in == 0) {
       float t = 0.f;
 #pragma unroll
       for (int i = 0; i < NW; ++i) t += part[slot * NW + i];
       constexpr float sc = float(4.0 / (double(N) * double(N)));
-      if constexpr (!STORE) *tile_out(tb, mm) = t * sc;
+      if constexpr (!STORE) *tile_out(tb, mm, &hint_out) = t * sc;
     }
   };
   if (m < nmaps) {
@@ -1233,7 +1235,7 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
     for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(first, 0, buf0, lane_in, W, it);
   }
   for (; m < nmaps; m += gridDim.x) {
-    const float* in_b = tile_in(tb, m);
+    const float* in_b = tile_in(tb, m, &hint_in);
     float parked[2][STRIPS][M];
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
@@ -1252,7 +1254,7 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
       const lds_ptr buf = cur ? buf1 : buf0;
       const lds_ptr nxt = cur ? buf0 : buf1;
       const bool more = (s + 1 < STRIPS) || (m + gridDim.x < nmaps);
-      const float* nsrc = (s + 1 < STRIPS || !more) ? in_b : tile_in(tb, m + gridDim.x);
+      const float* nsrc = (s + 1 < STRIPS || !more) ? in_b : tile_in(tb, m + gridDim.x, &hint_next);
       constexpr int nstrip = (s + 1 < STRIPS) ? s + 1 : 0;
 #if DCTS_F2_EXP != 1
       if (more) {

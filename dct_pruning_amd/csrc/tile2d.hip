@@ -724,6 +724,7 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  int hint_next = 0, hint_out = 0;  // tensor of the next / finished map (tile_item resumes its scan there)
   auto finish = [&]() DCTS_LAMBDA_INLINE {
     if (pending_m >= 0) {
       if (wave == 0 && lane_in == 0) {
@@ -731,7 +732,7 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
 #pragma unroll
         for (int i = 0; i < kT2Waves; ++i) t += partials[pending_slot * kT2Waves + i];
         constexpr float sc = float(4.0 / (double(Cfg::N) * double(Cfg::N)));
-        if constexpr (!STORE) *tile_out(tb, pending_m) = t * sc;  // the coefficient path has no energy output
+        if constexpr (!STORE) *tile_out(tb, pending_m, &hint_out) = t * sc;  // the coefficient path has no energy output
       }
       pending_m = -1;
     }
@@ -830,7 +831,7 @@ __device__ __forceinline__ void t2_body(const Src& tb, lds_ptr zbuf, lds_ptr raw
     // last loads' latency). 32 parked + 32 landing + 44 for a pass fit the 128 VGPRs of a 16-wave
     // workgroup; so do 64 landing + 44.
     const bool more = m + gridDim.x < nmaps;
-    const float* nsrc = tile_in(tb, more ? m + gridDim.x : m);
+    const float* nsrc = tile_in(tb, more ? m + gridDim.x : m, &hint_next);
     const unsigned nbytes = more ? (unsigned)(Cfg::N * Cfg::N * 4) : 0u;  // behind the last map: every load reads out of range
     static_assert(Cfg::hook_begin(3) <= t2_set_count(0, Cfg::VB), "a slot is loaded after its set has gone to LDS");
     auto trickle = [&](auto set) DCTS_LAMBDA_INLINE {

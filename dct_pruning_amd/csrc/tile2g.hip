@@ -279,25 +279,22 @@ struct G2Group {
   float* out;         // its energy
   int count;          // maps in the group (<= G; the last group of a tensor may be short)
 };
+// The launch's groups: tensor t owns groups [gbegin[t], gbegin[t + 1]) (host-computed; a TileBatch holds up to 32 tensors).
+// Which tensor a group belongs to is found WITHOUT memory: lane t keeps gbegin[t] in a register for the whole launch,
+// and the tensor of group grp is the number of lanes with gbegin <= grp, minus one (one compare + ballot). The first
+// version walked the table with dependent scalar loads every round: a third of a 72 x 72 round when sixteen small
+// tensors share the launch (U2-Net-p's step: 61 us for what one tensor of the same size takes 38 us).
+struct G2Batch {
+  TileBatch tb;
+  int gbegin[kTileItems + 1];  // gbegin[count] = all groups
+};
 template <int G>
-__device__ __forceinline__ long long g2_group_count(const TileBatch& tb) {
-  long long n = 0;
-  for (int t = 0; t < tb.count; ++t) n += (tb.begin[t + 1] - tb.begin[t] + G - 1) / G;
-  return n;
-}
-template <int G>
-__device__ __forceinline__ G2Group g2_group(const TileBatch& tb, long long grp) {
-  int t = 0;
-  long long g0 = 0;
-  for (;;) {
-    const long long ng = (tb.begin[t + 1] - tb.begin[t] + G - 1) / G;
-    if (t + 1 >= tb.count || grp < g0 + ng) break;
-    g0 += ng;
-    ++t;
-  }
-  t = __builtin_amdgcn_readfirstlane(t);
+__device__ __forceinline__ G2Group g2_group(const G2Batch& gb, int grp, int gbeg_lane) {
+  const unsigned long long ge = __builtin_amdgcn_ballot_w64(gbeg_lane <= grp);
+  const int t = __builtin_amdgcn_readfirstlane(__builtin_popcountll(ge) - 1);
+  const TileBatch& tb = gb.tb;
   const long long nt = tb.begin[t + 1] - tb.begin[t];
-  const long long m0 = (grp - g0) * G;
+  const long long m0 = (long long)(grp - gb.gbegin[t]) * G;
   G2Group r;
   const unsigned long long a = reinterpret_cast<unsigned long long>(tb.x[t] + m0 * tb.map_elems);
   r.base = reinterpret_cast<const float*>(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
@@ -308,8 +305,6 @@ __device__ __forceinline__ G2Group g2_group(const TileBatch& tb, long long grp) 
   return r;
 }
 
-// loads of item (g, p, q) for the sample slots [I0, I1) of the load order (set by set): buffer loads, reads
-// beyond the group's `bytes` return 0 (lanes without an item, maps beyond a short group, "no next group")
 // Load order of the sample slot PAIRS {(a, b), (a + 2, b)}, a & 2 == 0, as a * S + b: set 0's (rows a even),
 // then set 1's (a odd) - a pair's registers are free for the next round's samples once its set has gone to LDS.
 // Inside a set a-major: consecutive loads of a lane read the SAME rows of the map (slots b, b + 1 ... of row
@@ -454,7 +449,7 @@ __device__ __forceinline__ float g2_pass_dispatch(int vid, lds_ptr zset, lds_cpt
 }
 
 template <int L, int M, int G, bool STORE>
-__device__ __forceinline__ void g2_body(const TileBatch& tb, lds_ptr zbuf, lds_ptr rot, lds_ptr params, lds_ptr partials, float* leaf_out) {
+__device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr rot, lds_ptr params, lds_ptr partials, float* leaf_out) {
   using Cfg = G2Cfg<L, M, G>;
   constexpr int S = Cfg::S, N = Cfg::N, RS = Cfg::RS, BS = Cfg::BS, NROT = Cfg::NROT, NSETS = Cfg::NSETS, NBS = Cfg::NBS,
                 PPW = Cfg::PPW, NW = kG2Waves;
@@ -514,8 +509,10 @@ __device__ __forceinline__ void g2_body(const TileBatch& tb, lds_ptr zbuf, lds_p
       oo = ok ? gb + ((M - 1 - p) * N + (M - 1 - q)) * 4 : kOut;
     }
   };
-  const long long ngroups = g2_group_count<G>(tb);
-  long long grp = blockIdx.x;
+  const int ngroups = gb.gbegin[gb.tb.count];
+  // lane t: first group of tensor t (lanes beyond the tensors: never <= a group index)
+  const int gbeg_lane = lane_in < gb.tb.count ? gb.gbegin[lane_in < kTileItems ? lane_in : 0] : 0x7fffffff;
+  int grp = blockIdx.x;
   g2_v2f vp[S / 2][S];  // the lane's S x S samples: vp[g2_pi(a)][b].x = slot (a, b) for a & 2 == 0, .y = slot (a + 2, b)
   auto vget = [&](auto ia, auto ib) DCTS_LAMBDA_INLINE -> float {
     constexpr int a = decltype(ia)::value, b = decltype(ib)::value;
@@ -531,7 +528,7 @@ __device__ __forceinline__ void g2_body(const TileBatch& tb, lds_ptr zbuf, lds_p
     else
       vp[g2_pi(a)][b].x = val;
   };
-  G2Group cur = g2_group<G>(tb, grp);  // grid <= ngroups
+  G2Group cur = g2_group<G>(gb, grp, gbeg_lane);  // grid <= ngroups
   {
     int ee, eo, oe, oo;
     voffs(ee, eo, oe, oo);
@@ -595,14 +592,14 @@ __device__ __forceinline__ void g2_body(const TileBatch& tb, lds_ptr zbuf, lds_p
     lds_barrier();  // every consumer is done with the previous round's last set
     G2_STAMP(1);
     finish();
-    const bool more = grp + gridDim.x < ngroups;
-    const G2Group nxt = g2_group<G>(tb, more ? grp + gridDim.x : grp);
+    const bool more = grp + (int)gridDim.x < ngroups;
+    const G2Group nxt = g2_group<G>(gb, more ? grp + (int)gridDim.x : grp, launder(gbeg_lane));
 #if DCTS_G2_EXP == 3
     const unsigned nbytes = 0u;
 #else
     const unsigned nbytes = more ? (unsigned)(nxt.count * N * N * 4) : 0u;  // no next group: every load reads "out of range"
 #endif
-    const long long map0 = STORE ? (grp * G) : 0;  // coefficient path: one tensor, groups are consecutive maps
+    const long long map0 = STORE ? ((long long)grp * G) : 0;  // coefficient path: one tensor, groups are consecutive maps
     float e_acc = 0.f;
     dcts::static_for<NSETS>([&](auto iset) DCTS_LAMBDA_INLINE {
       constexpr int SET = decltype(iset)::value;
@@ -709,13 +706,13 @@ constexpr int g2_wgs_per_cu() {
 }
 
 template <int L, int M, int G, bool STORE>
-__global__ __launch_bounds__((64 * kG2Waves), (4 * g2_wgs_per_cu<L, M, G>())) void k_tile2g(TileBatch tb, float* leaf_out) {
+__global__ __launch_bounds__((64 * kG2Waves), (4 * g2_wgs_per_cu<L, M, G>())) void k_tile2g(G2Batch gb, float* leaf_out) {
   using Cfg = G2Cfg<L, M, G>;
   __shared__ __attribute__((aligned(16))) float zbuf[Cfg::ZSET];
   __shared__ __attribute__((aligned(16))) float rot[(Cfg::NROT > 0 ? Cfg::NROT : 1) * M * 4];
   __shared__ __attribute__((aligned(16))) float params[Cfg::NSETS * Cfg::NBS * 8];
   __shared__ float partials[2 * kG2Waves * G];
-  g2_body<L, M, G, STORE>(tb, (lds_ptr)zbuf, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
+  g2_body<L, M, G, STORE>(gb, (lds_ptr)zbuf, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
 }
 
 // X(N, L, M, G)
@@ -733,20 +730,31 @@ int g2_num_cus() {
   return ncu;
 }
 
+// groups of G maps, never across tensors; DCTS_E_SHAPE if they do not fit an int (2^31 groups: not a real launch)
 template <int G>
-long long g2_host_groups(const TileBatch& tb) {
+int g2_make_batch(const TileBatch& tb, G2Batch& gb) {
+  gb.tb = tb;
   long long n = 0;
-  for (int t = 0; t < tb.count; ++t) n += (tb.begin[t + 1] - tb.begin[t] + G - 1) / G;
-  return n;
+  for (int t = 0; t < kTileItems; ++t) {
+    gb.gbegin[t] = (int)n;
+    if (t < tb.count) n += (tb.begin[t + 1] - tb.begin[t] + G - 1) / G;
+    if (n > 0x7fffff00LL) return DCTS_E_SHAPE;
+  }
+  gb.gbegin[kTileItems] = (int)n;
+  for (int t = tb.count; t <= kTileItems; ++t) gb.gbegin[t] = (int)n;
+  return DCTS_OK;
 }
 
 template <int L, int M, int G>
 int launch_tile2g(const TileBatch& tb, hipStream_t st) {
-  const long long groups = g2_host_groups<G>(tb);
+  G2Batch gb;
+  const int rc = g2_make_batch<G>(tb, gb);
+  if (rc) return rc;
+  const long long groups = gb.gbegin[tb.count];
   if (groups < 1) return DCTS_OK;
   const long long cap = (long long)g2_num_cus() * g2_wgs_per_cu<L, M, G>();  // one residency, persistent over rounds
   const long long grid = groups < cap ? groups : cap;
-  hipLaunchKernelGGL((k_tile2g<L, M, G, false>), dim3((unsigned)grid), dim3(64 * kG2Waves), 0, st, tb, (float*)nullptr);
+  hipLaunchKernelGGL((k_tile2g<L, M, G, false>), dim3((unsigned)grid), dim3(64 * kG2Waves), 0, st, gb, (float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -766,10 +774,13 @@ int coeff_tile2g(const float* x, long long nmaps, float* out, float* scratch, lo
     tb.map_elems = (long long)N * N;
     tb.total = nb;
     tb.count = 1;
-    const long long groups = (nb + G - 1) / G;
+    G2Batch gb;
+    const int rcb = g2_make_batch<G>(tb, gb);
+    if (rcb) return rcb;
+    const long long groups = gb.gbegin[1];
     const long long grid = groups < g2_num_cus() ? groups : g2_num_cus();
-  #ifndef DCTS_G2_NOSTORE
-    hipLaunchKernelGGL((k_tile2g<L, M, G, true>), dim3((unsigned)grid), dim3(64 * kG2Waves), 0, st, tb, scratch);
+#ifndef DCTS_G2_NOSTORE
+    hipLaunchKernelGGL((k_tile2g<L, M, G, true>), dim3((unsigned)grid), dim3(64 * kG2Waves), 0, st, gb, scratch);
 #else
     (void)grid;
     return DCTS_E_UNSUPPORTED;  // development build without the coefficient instantiations
