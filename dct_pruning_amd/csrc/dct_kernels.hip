@@ -64,7 +64,9 @@ int dispatch_fused2_coeff(int N, const float* x, long long nmaps, float* out, fl
 int dispatch_tile2d_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
 // tile2g.hip: mid-size edges as a 2-D radix split with several maps per round
 int has_tile2g(int N);
+int has_tile2g_pad(int N);
 int dispatch_tile2g(int N, const void* tile_batch, hipStream_t st);
+int dispatch_tile2g_pad(int N, const void* tile_batch, hipStream_t st);  // tiles with the odd front pad (N = H + 1)
 int dispatch_tile2g_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps, hipStream_t st);
 }  // namespace dctsi
 
@@ -2473,6 +2475,8 @@ int tile_family(int HP, int algo, long long nmaps) {
 }
 int dispatch_tile_family(int fam, int HP, const TileBatch& tb, hipStream_t st) {
   switch (fam) {
+    case 6:
+      return dctsi::dispatch_tile2g_pad(HP, &tb, st);
     case 5:
       return dctsi::dispatch_tile2g(HP, &tb, st);
     case 4:
@@ -2598,14 +2602,19 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     return dispatch_codelet<STORE>((int)HP, (int)WP, pad, g, out, st);
   }
   if constexpr (!STORE) {
-    // every split kernel stages with 16-byte direct-to-LDS loads: a base that is only 4-byte aligned
-    // takes the direct kernel
+    // every split kernel stages with 16-byte direct-to-LDS loads: a base that is only 4-byte aligned takes the
+    // direct kernel - except where tile2g.hip has the shape: it gathers single dwords and needs neither the alignment
+    // nor (for 71 / 79 / 143 / 159: the cv2 path on odd maps) an unpadded tile
     const bool aligned16 = (reinterpret_cast<uintptr_t>(x + (long long)c_begin * strideC) & 15) == 0;
-    const bool split_ok = has_split(HP, WP) && pad == 0 && strideH == W && g.contiguous &&
-                          strideC == H * W && aligned16;
+    const bool dense_maps = H == W && strideH == W && g.contiguous && strideC == H * W;
+    const bool split_ok = has_split(HP, WP) && pad == 0 && dense_maps && aligned16;
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
     if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) {
-      const int fam = (split_ok && aligned16) ? tile_family((int)HP, algo, g.nmaps) : 0;
+      int fam = (split_ok && aligned16) ? tile_family((int)HP, algo, g.nmaps) : 0;
+      if (!fam && dense_maps && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_TILE2D)) {
+        if (pad == 0 && !aligned16 && dctsi::has_tile2g((int)HP)) fam = 5;
+        if (pad == 1 && dctsi::has_tile2g_pad((int)HP)) fam = 6;
+      }
       if (fam) {
         TileBatch tb;
         for (int i = 0; i < kTileItems; ++i) {
@@ -2880,7 +2889,8 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
   // large tiles with a single-launch kernel: the dense tensors go into ONE launch per 32 of them (their
   // maps form one index space: a CU that would get a fraction of a map from one small tensor now
   // draws from all of them); results are those of one call per tensor, bit for bit
-  const int fam = (pad == 0 && H == W && has_split(HP, WP)) ? tile_family((int)HP, DCTS_ALGO_AUTO, 0) : 0;
+  const int fam = (pad == 0 && H == W && has_split(HP, WP)) ? tile_family((int)HP, DCTS_ALGO_AUTO, 0)
+                  : ((pad == 1 && H == W && dctsi::has_tile2g_pad((int)HP)) ? 6 : 0);
   TileBatch tb;
   int nb = 0;
   auto flush = [&]() -> int {
@@ -2899,8 +2909,9 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
   for (int32_t i = 0; i < count; ++i) {
     const dcts_tensor_item& t = items[i];
     const float* x0 = t.x + (int64_t)t.c_begin * t.strideC;
+    // (the dword-gathering tile2g kernels - families 5 and 6 - take any 4-byte-aligned base, the others need 16)
     const bool dense = fam && t.strideC == H * W && (t.N == 1 || t.strideN == (int64_t)t.c_count * t.strideC) &&
-                       (reinterpret_cast<uintptr_t>(x0) & 15) == 0;
+                       ((reinterpret_cast<uintptr_t>(x0) & 15) == 0 || fam >= 5);
     if (dense) {
       if (nb == 0) tb.begin[0] = 0;
       tb.x[nb] = x0;

@@ -37,6 +37,8 @@ int dispatch_tile2g(int N, const void* tile_batch, hipStream_t st);
 int dispatch_tile2g_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps,
                           hipStream_t st);
 int has_tile2g(int N);
+int has_tile2g_pad(int N);
+int dispatch_tile2g_pad(int N, const void* tile_batch, hipStream_t st);
 }  // namespace dctsi
 
 namespace {
@@ -336,20 +338,41 @@ constexpr int g2_pi(int a) { return (a & 1) | ((a & 4) >> 1); }  // which regist
 // the same instruction (its lane offset points two row slots further): half the instructions. g2_exchange() hands
 // each lane its own two samples afterwards. Reads beyond the group's `bytes` return 0 (lanes without an item, maps
 // beyond a short group, "no next group").
-template <int L, int M, int G, int NSETS, bool PAIR, int I0, int I1>
-__device__ __forceinline__ void g2_load_pairs(const float* base, unsigned bytes, int voff_ee, int voff_eo, int voff_oe, int voff_oo,
-                                              g2_v2f (&vp)[(1 << L) / 2][1 << L]) {
-  constexpr int S = 1 << L, N = M * S;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+// PAD (the cv2 path of torch2dct, utils/common.py:235-236, for an odd H: one zero row AND one zero column in front): the map
+// in memory is (N-1) x (N-1) with row pitch N-1; sample (r, c) of the padded tile is x[r-1][c-1], and row 0 / column 0 are
+// zeros. The descriptor's base is moved N floats in front of the group's first map, so that offset (r * (N-1) + c) * 4
+// addresses x[r-1][c-1]; row 0 is only touched by row slot a = 0 of the lanes with p = 0, column 0 by column slot b = 0 of
+// the lanes with q = 0: those lanes get an out-of-range offset for those slots (zeros, no request) - G2Voffs::a0 / b0 / ab.
+struct G2Voffs {
+  int ee, eo, oe, oo;      // (row slot parity, column slot parity): ascending / descending p~, q~
+  int ee_a0, eo_a0;        // PAD: row slot 0     (zero row for p == 0)
+  int ee_b0, oe_b0;        // PAD: column slot 0  (zero column for q == 0)
+  int ee_ab;               // PAD: slot (0, 0)
+};
+template <int L, int M, int G, int NSETS, bool PAIR, int PAD, int I0, int I1>
+__device__ __forceinline__ void g2_load_pairs(const float* base, unsigned bytes, const G2Voffs& vo, g2_v2f (&vp)[(1 << L) / 2][1 << L]) {
+  constexpr int S = 1 << L, N = M * S, NP = N - PAD;  // NP: row pitch in memory
+  static_assert(!(PAIR && PAD), "the paired loads assume aligned column pairs");
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base) - PAD * (NP + 1), 0,
+                                                                      bytes ? bytes + PAD * (NP + 1) * 4 : 0u, 0x00020000);
+  auto pick = [&](auto ia, auto ib) DCTS_LAMBDA_INLINE -> int {
+    constexpr int a = decltype(ia)::value, b = decltype(ib)::value;
+    if constexpr (PAD != 0 && a == 0 && b == 0) return vo.ee_ab;
+    if constexpr (PAD != 0 && a == 0) return (b % 2 == 0) ? vo.ee_a0 : vo.eo_a0;
+    if constexpr (PAD != 0 && b == 0) return (a % 2 == 0) ? vo.ee_b0 : vo.oe_b0;
+    return (a % 2 == 0) ? ((b % 2 == 0) ? vo.ee : vo.eo) : ((b % 2 == 0) ? vo.oe : vo.oo);
+  };
   dcts::static_for<(I1 > I0 ? I1 - I0 : 0)>([&](auto ii) DCTS_LAMBDA_INLINE {
     constexpr int sl = kG2LoadOrder<L, NSETS>.pair[I0 + decltype(ii)::value];
     constexpr int a = sl / S, b = sl % S;
-    const int voff = (a % 2 == 0) ? ((b % 2 == 0) ? voff_ee : voff_eo) : ((b % 2 == 0) ? voff_oe : voff_oo);
     if constexpr (PAIR) {
-      vp[g2_pi(a)][b] = __builtin_bit_cast(g2_v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (a * M * N + b * M) * 4, 0));
+      vp[g2_pi(a)][b] = __builtin_bit_cast(g2_v2f, __builtin_amdgcn_raw_buffer_load_b64(rs, pick(std::integral_constant<int, a>{}, std::integral_constant<int, b>{}),
+                                                                                         (a * M * NP + b * M) * 4, 0));
     } else {  // every lane loads its own two samples of the slot pair, one dword each (the offsets point at its own column)
-      vp[g2_pi(a)][b].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (a * M * N + b * M) * 4, 0));
-      vp[g2_pi(a)][b].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, ((a + 2) * M * N + b * M) * 4, 0));
+      vp[g2_pi(a)][b].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          rs, pick(std::integral_constant<int, a>{}, std::integral_constant<int, b>{}), (a * M * NP + b * M) * 4, 0));
+      vp[g2_pi(a)][b].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+          rs, pick(std::integral_constant<int, a + 2>{}, std::integral_constant<int, b>{}), ((a + 2) * M * NP + b * M) * 4, 0));
     }
   });
 }
@@ -448,7 +471,7 @@ __device__ __forceinline__ float g2_pass_dispatch(int vid, lds_ptr zset, lds_cpt
   return g2_pass<L, M, G, 1, 1, STORE>(zset, pp, li, map_a, map_b, leaf_out, map0, count);
 }
 
-template <int L, int M, int G, bool STORE>
+template <int L, int M, int G, bool STORE, int PAD>
 __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr rot, lds_ptr params, lds_ptr partials, float* leaf_out) {
   using Cfg = G2Cfg<L, M, G>;
   constexpr int S = Cfg::S, N = Cfg::N, RS = Cfg::RS, BS = Cfg::BS, NROT = Cfg::NROT, NSETS = Cfg::NSETS, NBS = Cfg::NBS,
@@ -488,25 +511,38 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
   const int ig = ok ? idx / (M * M) : 0;
   const int ir = ok ? idx - ig * (M * M) : 0;
   const int ip = ir / M, iq = ir - ip * M;
-  // lane offsets of the four mirrored quadrant kinds (8-byte pairs: the even column of the lane pair; odd lanes two
-  // row slots further, see g2_load_pairs); lanes without an item read out of range (zeros, no traffic)
+  // lane offsets of the four mirrored quadrant kinds (with DCTS_G2_PAIR, 8-byte pairs: the even column of the lane pair, odd
+  // lanes two row slots further, see g2_load_pairs); lanes without an item read out of range (zeros, no traffic)
   static_assert(M % 2 == 0, "lane pairs share a row");
+  static_assert(!(STORE && PAD), "the coefficient path takes unpadded tiles");
   constexpr int kOut = 0x7ffffff0;
-  auto voffs = [&](int& ee, int& eo, int& oe, int& oo) DCTS_LAMBDA_INLINE {
+  constexpr int NPITCH = N - PAD, MAPB = NPITCH * NPITCH * 4;  // row pitch (floats) and bytes of a map in memory
+  // (`cnt`: maps in the group the offsets are for. Lanes of maps beyond a short group are out of range by their own
+  // offset - with PAD the descriptor is N floats longer than the group's maps, so the range check alone would let the
+  // first row of the missing map through, up to a map's length past the end of the tensor once the slot offset is added)
+  auto voffs = [&](G2Voffs& vo, int cnt) DCTS_LAMBDA_INLINE {
     const int p = launder(ip), q = launder(iq), g = launder(ig);
+    const bool ok = launder(idx) < Cfg::ITEMS && g < cnt;
     if constexpr (Cfg::PAIR) {
       const int q2 = q & ~1;
-      const int gb = g * (N * N * 4) + ((q & 1) ? 2 * M * N * 4 : 0);
-      ee = ok ? gb + (p * N + q2) * 4 : kOut;
-      eo = ok ? gb + (p * N + (M - 2 - q2)) * 4 : kOut;
-      oe = ok ? gb + ((M - 1 - p) * N + q2) * 4 : kOut;
-      oo = ok ? gb + ((M - 1 - p) * N + (M - 2 - q2)) * 4 : kOut;
+      const int gbo = g * MAPB + ((q & 1) ? 2 * M * NPITCH * 4 : 0);
+      vo.ee = ok ? gbo + (p * NPITCH + q2) * 4 : kOut;
+      vo.eo = ok ? gbo + (p * NPITCH + (M - 2 - q2)) * 4 : kOut;
+      vo.oe = ok ? gbo + ((M - 1 - p) * NPITCH + q2) * 4 : kOut;
+      vo.oo = ok ? gbo + ((M - 1 - p) * NPITCH + (M - 2 - q2)) * 4 : kOut;
     } else {
-      const int gb = g * (N * N * 4);
-      ee = ok ? gb + (p * N + q) * 4 : kOut;
-      eo = ok ? gb + (p * N + (M - 1 - q)) * 4 : kOut;
-      oe = ok ? gb + ((M - 1 - p) * N + q) * 4 : kOut;
-      oo = ok ? gb + ((M - 1 - p) * N + (M - 1 - q)) * 4 : kOut;
+      const int gbo = g * MAPB;
+      vo.ee = ok ? gbo + (p * NPITCH + q) * 4 : kOut;
+      vo.eo = ok ? gbo + (p * NPITCH + (M - 1 - q)) * 4 : kOut;
+      vo.oe = ok ? gbo + ((M - 1 - p) * NPITCH + q) * 4 : kOut;
+      vo.oo = ok ? gbo + ((M - 1 - p) * NPITCH + (M - 1 - q)) * 4 : kOut;
+    }
+    if constexpr (PAD != 0) {
+      vo.ee_a0 = p == 0 ? kOut : vo.ee;
+      vo.eo_a0 = p == 0 ? kOut : vo.eo;
+      vo.ee_b0 = q == 0 ? kOut : vo.ee;
+      vo.oe_b0 = q == 0 ? kOut : vo.oe;
+      vo.ee_ab = (p == 0 || q == 0) ? kOut : vo.ee;
     }
   };
   const int ngroups = gb.gbegin[gb.tb.count];
@@ -530,9 +566,9 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
   };
   G2Group cur = g2_group<G>(gb, grp, gbeg_lane);  // grid <= ngroups
   {
-    int ee, eo, oe, oo;
-    voffs(ee, eo, oe, oo);
-    g2_load_pairs<L, M, G, NSETS, Cfg::PAIR, 0, S * S / 2>(cur.base, (unsigned)(cur.count * N * N * 4), ee, eo, oe, oo, vp);
+    G2Voffs vo;
+    voffs(vo, cur.count);
+    g2_load_pairs<L, M, G, NSETS, Cfg::PAIR, PAD, 0, S * S / 2>(cur.base, (unsigned)(cur.count * MAPB), vo, vp);
   }
   __builtin_amdgcn_sched_barrier(0);
   long long pending = -1;  // a round whose partials wait for the workgroup sum
@@ -597,7 +633,7 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
 #if DCTS_G2_EXP == 3
     const unsigned nbytes = 0u;
 #else
-    const unsigned nbytes = more ? (unsigned)(nxt.count * N * N * 4) : 0u;  // no next group: every load reads "out of range"
+    const unsigned nbytes = more ? (unsigned)(nxt.count * MAPB) : 0u;  // no next group: every load reads "out of range"
 #endif
     const long long map0 = STORE ? ((long long)grp * G) : 0;  // coefficient path: one tensor, groups are consecutive maps
     float e_acc = 0.f;
@@ -634,8 +670,8 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
       if (wave >= NW / 2) __builtin_amdgcn_s_sleep(DCTS_G2_SKEW);
 #endif
       // ---- leaf passes of this wave, the next round's samples trickled into the vacated registers ---------
-      int ee, eo, oe, oo;
-      voffs(ee, eo, oe, oo);
+      G2Voffs vo;
+      voffs(vo, nxt.count);
       dcts::static_for<PPW>([&](auto ipass) DCTS_LAMBDA_INLINE {
         constexpr int PASS = decltype(ipass)::value;
         const int li = PASS * NW + wave;  // G2Sched deals the blocks in snake order of their cost
@@ -645,14 +681,14 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
         constexpr int i0 = SET * Cfg::PER_SET + (Cfg::PER_SET * PASS) / PPW, i1 = SET * Cfg::PER_SET + (Cfg::PER_SET * (PASS + 1)) / PPW;
         constexpr int ih = i0 + (i1 - i0) / 2;
         G2_STAMP(4 + 4 * SET);
-        g2_load_pairs<L, M, G, NSETS, Cfg::PAIR, i0, ih>(nxt.base, nbytes, ee, eo, oe, oo, vp);
+        g2_load_pairs<L, M, G, NSETS, Cfg::PAIR, PAD, i0, ih>(nxt.base, nbytes, vo, vp);
         __builtin_amdgcn_sched_barrier(0);
         G2_STAMP(13);
         float e = g2_pass_dispatch<L, M, G, STORE>(vid, zbuf, pp, li, launder(map_a), launder(map_b), leaf_out, map0, cur.count);
         asm volatile("" : "+v"(e));
         __builtin_amdgcn_sched_barrier(0);
         G2_STAMP(4 + 4 * SET);
-        g2_load_pairs<L, M, G, NSETS, Cfg::PAIR, ih, i1>(nxt.base, nbytes, ee, eo, oe, oo, vp);
+        g2_load_pairs<L, M, G, NSETS, Cfg::PAIR, PAD, ih, i1>(nxt.base, nbytes, vo, vp);
         __builtin_amdgcn_sched_barrier(0);
         G2_STAMP(13);
         e_acc += e;
@@ -705,19 +741,23 @@ constexpr int g2_wgs_per_cu() {
 #endif
 }
 
-template <int L, int M, int G, bool STORE>
+template <int L, int M, int G, bool STORE, int PAD = 0>
 __global__ __launch_bounds__((64 * kG2Waves), (4 * g2_wgs_per_cu<L, M, G>())) void k_tile2g(G2Batch gb, float* leaf_out) {
   using Cfg = G2Cfg<L, M, G>;
   __shared__ __attribute__((aligned(16))) float zbuf[Cfg::ZSET];
   __shared__ __attribute__((aligned(16))) float rot[(Cfg::NROT > 0 ? Cfg::NROT : 1) * M * 4];
   __shared__ __attribute__((aligned(16))) float params[Cfg::NSETS * Cfg::NBS * 8];
   __shared__ float partials[2 * kG2Waves * G];
-  g2_body<L, M, G, STORE>(gb, (lds_ptr)zbuf, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
+  g2_body<L, M, G, STORE, PAD>(gb, (lds_ptr)zbuf, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
 }
 
 // X(N, L, M, G)
 #ifndef DCTS_TILE2G_TABLE
 #define DCTS_TILE2G_TABLE(X) X(72, 2, 18, 3) X(80, 2, 20, 2) X(112, 3, 14, 4) X(128, 3, 16, 4) X(144, 3, 18, 3) X(160, 3, 20, 2)
+#endif
+// ... and with the odd front pad (71, 79, 143, 159 -> 72, 80, 144, 160)
+#ifndef DCTS_TILE2G_PAD_TABLE
+#define DCTS_TILE2G_PAD_TABLE(X) X(72, 2, 18, 3) X(80, 2, 20, 2) X(144, 3, 18, 3) X(160, 3, 20, 2)
 #endif
 
 int g2_num_cus() {
@@ -745,7 +785,7 @@ int g2_make_batch(const TileBatch& tb, G2Batch& gb) {
   return DCTS_OK;
 }
 
-template <int L, int M, int G>
+template <int L, int M, int G, int PAD = 0>
 int launch_tile2g(const TileBatch& tb, hipStream_t st) {
   G2Batch gb;
   const int rc = g2_make_batch<G>(tb, gb);
@@ -754,7 +794,7 @@ int launch_tile2g(const TileBatch& tb, hipStream_t st) {
   if (groups < 1) return DCTS_OK;
   const long long cap = (long long)g2_num_cus() * g2_wgs_per_cu<L, M, G>();  // one residency, persistent over rounds
   const long long grid = groups < cap ? groups : cap;
-  hipLaunchKernelGGL((k_tile2g<L, M, G, false>), dim3((unsigned)grid), dim3(64 * kG2Waves), 0, st, gb, (float*)nullptr);
+  hipLaunchKernelGGL((k_tile2g<L, M, G, false, PAD>), dim3((unsigned)grid), dim3(64 * kG2Waves), 0, st, gb, (float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -810,6 +850,19 @@ extern "C" int g2_dev_run(const float* x, long long nmaps, int edge, float* out,
   tb.count = 1;
   return dctsi::dispatch_tile2g(edge, &tb, reinterpret_cast<hipStream_t>(stream));
 }
+extern "C" int g2_dev_run_pad(const float* x, long long nmaps, int edge_padded, float* out, void* stream) {
+  TileBatch tb;
+  for (int i = 0; i < kTileItems; ++i) {
+    tb.x[i] = x;
+    tb.out[i] = out;
+    tb.begin[i] = 0;
+  }
+  tb.begin[1] = tb.begin[kTileItems] = nmaps;
+  tb.map_elems = (long long)(edge_padded - 1) * (edge_padded - 1);
+  tb.total = nmaps;
+  tb.count = 1;
+  return dctsi::dispatch_tile2g_pad(edge_padded, &tb, reinterpret_cast<hipStream_t>(stream));
+}
 extern "C" int g2_dev_coeff(const float* x, long long nmaps, int edge, float* out, float* scratch, long long scratch_maps, void* stream) {
   return dctsi::dispatch_tile2g_coeff(edge, x, nmaps, out, scratch, scratch_maps, reinterpret_cast<hipStream_t>(stream));
 }
@@ -843,6 +896,26 @@ int dispatch_tile2g(int N, const void* tile_batch, hipStream_t st) {
       return DCTS_E_UNSUPPORTED;
   }
 #undef DCTS_CASE
+}
+// odd front pad (tile edge N = H + 1 after the pad; the maps in memory are H x H, tb.map_elems = H * H): the AUTO shapes only
+int dispatch_tile2g_pad(int N, const void* tile_batch, hipStream_t st) {
+  const TileBatch& tb = *static_cast<const TileBatch*>(tile_batch);
+#define DCTS_CASE(N_, L_, M_, G_) \
+  case N_:                        \
+    return launch_tile2g<L_, M_, G_, 1>(tb, st);
+  switch (N) {
+    DCTS_TILE2G_PAD_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+  }
+#undef DCTS_CASE
+}
+int has_tile2g_pad(int N) {
+#define DCTS_CASE(N_, L_, M_, G_) \
+  if (N == N_) return 1;
+  DCTS_TILE2G_PAD_TABLE(DCTS_CASE)
+#undef DCTS_CASE
+  return 0;
 }
 int dispatch_tile2g_coeff(int N, const float* x, long long nmaps, float* out, float* scratch, long long scratch_maps,
                           hipStream_t st) {

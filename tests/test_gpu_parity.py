@@ -223,6 +223,37 @@ def test_odd_front_pad(n):
     assert rel_err(got[:1, :3].cpu(), ref) <= RTOL
 
 
+@pytest.mark.parametrize("n", [71, 79, 143, 159])
+def test_odd_front_pad_mid_size_tiles(n):
+    """cv2 path on odd maps whose padded edge has a tile2g kernel (71 -> 72, 79 -> 80, 143 -> 144, 159 -> 160): the kernel
+    gathers the (n x n) map with row pitch n and reads the zero row / column as out-of-range offsets. Map counts around the
+    round size (short last groups), dead channels, a 4-byte-aligned base, several tensors in one launch, bit-reproducible;
+    the direct kernel (which pads in LDS) as a second witness."""
+    for nmaps, seed in [(1, 0), (2, 1), (3, 2), (4, 3), (7, 4), (260, 5), (771, 6)]:
+        x = synth(1, nmaps, n, n, 470 + n + seed)
+        got = dpa.energy_nc(x.cuda(), pad_front_if_odd=True)
+        check(x, got, pad_front_if_odd=True)
+        assert torch.equal(got, dpa.energy_nc(x.cuda(), pad_front_if_odd=True))
+        assert torch.equal(got, dpa.energy_nc(x.cuda(), pad_front_if_odd=True, algo=dpa.ALGO_TILE2D))  # that is what AUTO ran
+        assert rel_err(got.cpu(), dpa.energy_nc(x.cuda(), pad_front_if_odd=True, algo=dpa.ALGO_DIRECT).cpu()) <= 1e-5
+    x = synth(2, 6, n, n, 31 + n)
+    flat = torch.zeros(x.numel() + 1)
+    flat[1:] = x.reshape(-1)
+    view = flat.cuda()[1:].view(2, 6, n, n)  # base address only 4-byte aligned
+    check(x, dpa.energy_nc(view, pad_front_if_odd=True), pad_front_if_odd=True)
+    tensors = [synth(1 + (i % 2), c, n, n, 900 + i + n).cuda() for i, c in enumerate([1, 2, 3, 5, 16, 4])]
+    outs = dpa.energy_multi([(t, 0, None) for t in tensors], pad_front_if_odd=True)
+    for t, e in zip(tensors, outs):
+        assert torch.equal(e, dpa.energy_nc(t, pad_front_if_odd=True))
+        check(t.cpu(), e, pad_front_if_odd=True)
+    # the last map of an allocation: nothing may be read behind it (the missing maps of a short group are out of range
+    # by their own offsets, not by the descriptor's length) - a tensor that ends exactly at the end of its buffer
+    buf = torch.empty(5 * n * n, device="cuda")
+    t = synth(1, 5, n, n, 77)
+    buf.copy_(t.reshape(-1))
+    check(t, dpa.energy_nc(buf.view(1, 5, n, n), pad_front_if_odd=True), pad_front_if_odd=True)
+
+
 @pytest.mark.parametrize("n", [8, 10, 36])
 def test_pad_flag_is_noop_for_even(n):
     x = synth(2, 4, n, n, 50)
@@ -498,8 +529,9 @@ def test_weighted_calls_of_several_shapes_share_one_workspace_safely():
 
 @pytest.mark.parametrize("n", [72, 288])
 def test_large_tile_with_a_4_byte_aligned_base(n):
-    """Every split-family kernel stages with 16-byte direct-to-LDS loads; a view whose base is only 4-byte
-    aligned takes the direct kernel under AUTO and is refused by an explicit large-tile family."""
+    """Every split-family kernel stages with 16-byte direct-to-LDS loads; a view whose base is only 4-byte aligned is
+    refused by those families. Under AUTO it takes the direct kernel (288) or, where tile2g.hip has the shape (72: it gathers
+    single dwords), that kernel - and then gives the bits of the aligned tensor."""
     from dct_pruning_amd._lib import DctScoreError
     c = 3
     x = synth(1, c, n, n, 700 + n)
@@ -516,3 +548,5 @@ def test_large_tile_with_a_4_byte_aligned_base(n):
         assert ei.value.code == -6  # DCTS_E_UNSUPPORTED
     # the aligned tensor itself goes through the large-tile kernel and agrees
     assert rel_err(dpa.energy_nc(x.cuda()).cpu(), got) <= 1e-5
+    if n == 72:
+        assert torch.equal(dpa.energy_nc(x.cuda()).cpu(), got)  # the same kernel, aligned or not
