@@ -70,6 +70,7 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL needs it)
         from dct_pruning_amd import sharding
         # bounded bring-up: a rank that cannot reach the others prints {"error": ...} and exits 3 (sharding.py)
         sharding.init_process_group("gloo" if rehearse else "nccl", device=dev, what="importance_generation.py")
