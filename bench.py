@@ -255,6 +255,8 @@ def self_launch(n):
 
 
 def main():
+    # before the first HIP call: this pool's driver only supports dmabuf IPC, RCCL fails with hipIpcGetMemHandle otherwise
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     if args.batch is None:
         args.batch = 12 if args.net == "u2netp" else 256
@@ -277,7 +279,6 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL needs it)
         from dct_pruning_amd import sharding as _sh
         # bounded bring-up: a rank that cannot reach the others prints {"error": ...} and exits 3 (sharding.py)
         _sh.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world, device=dev, what="bench.py")

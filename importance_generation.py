@@ -58,6 +58,8 @@ def load_checkpoint(net, args):
 
 
 def main(argv=None):
+    # before the first HIP call: this pool's driver only supports dmabuf IPC, RCCL fails with hipIpcGetMemHandle otherwise
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("importance_generation.py needs a GPU: the score path has no CPU fallback")
@@ -70,7 +72,6 @@ def main(argv=None):
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL needs it)
         from dct_pruning_amd import sharding
         # bounded bring-up: a rank that cannot reach the others prints {"error": ...} and exits 3 (sharding.py)
         sharding.init_process_group("gloo" if rehearse else "nccl", device=dev, what="importance_generation.py")
