@@ -39,6 +39,12 @@
 #ifndef DCTS_TU
 #define DCTS_TU 0
 #endif
+#ifndef DCTS_ADDTID
+// ds_write_addtid_b32 for the codelet kernel's transposing stores where a wave holds one map (edges 36 ... 64): same box,
+// 200 MB launches, % of the HBM peak: 56: 60.7 -> 61.5-62.3, 48: 60.8 -> 63.0, 36: 52.9 -> 54.0, 64: 52.9 -> 54.2; the
+// 4.3 GB in-step launch is unchanged within noise (the kernel is VALU-bound there). Bit-identical results.
+#define DCTS_ADDTID 1
+#endif
 #ifndef DCTS_F2_EXP
 #define DCTS_F2_EXP 0  // timing experiments on k_split_fused2 (wrong results): 1 no staging loads, 2 no pass-1 butterflies, 3 no pass-2 butterflies, 4 no codelet arithmetic
 #endif
@@ -120,6 +126,19 @@ struct CodeletCfg {
   static constexpr int GRID_WAVES_PER_CU = (HP * WP >= 48 * 48) ? 256 : ((HP * WP >= 8 * 8) ? 512 : 32);
 };
 
+// four lane-consecutive LDS stores at byte offsets O0..O3 from `base` (an LDS byte address below 64 KiB: M0[15:0])
+template <int O0, int O1, int O2, int O3>
+__device__ __forceinline__ void lds_write_addtid4(unsigned base, float a, float b, float c, float d) {
+  static_assert(O3 < 65536 && O0 >= 0, "16-bit offset field");
+  asm volatile(
+      "s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+      "ds_write_addtid_b32 %1 offset:%5\n\tds_write_addtid_b32 %2 offset:%6\n\t"
+      "ds_write_addtid_b32 %3 offset:%7\n\tds_write_addtid_b32 %4 offset:%8"
+      :
+      : "s"(base), "v"(a), "v"(b), "v"(c), "v"(d), "n"(O0), "n"(O1), "n"(O2), "n"(O3)
+      : "memory", "m0");
+}
+
 // one group of G maps: both passes, the LDS transpose and the reduction (see the header comment)
 template <int HP, int WP, int PAD, bool STORE_COEFF>
 __device__ __forceinline__ void codelet_group(const MapGeom& g, float* __restrict__ out, long long grp,
@@ -158,6 +177,19 @@ __device__ __forceinline__ void codelet_group(const MapGeom& g, float* __restric
   float y[HP];
   dcts::Dct2<HP>::run(xr, y);
   y[0] *= dcts::kInvSqrt2;
+#if DCTS_ADDTID
+  if constexpr (G == 1 && HP % 4 == 0) {
+    // one map per wave: lane = column, so row kk of the transposed slab is lane-consecutive words - ds_write_addtid_b32
+    // (address = M0 + offset + 4 * lane: no address VGPR, 2 cycles per wave instruction instead of 4)
+    if (act1) {
+      const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(lds_ptr)my);  // the wave's slab: uniform
+      dcts::static_for<HP / 4>([&](auto i) DCTS_LAMBDA_INLINE {
+        constexpr int k0 = 4 * decltype(i)::value;
+        lds_write_addtid4<k0 * S * 4, (k0 + 1) * S * 4, (k0 + 2) * S * 4, (k0 + 3) * S * 4>(base, y[k0], y[k0 + 1], y[k0 + 2], y[k0 + 3]);
+      });
+    }
+  } else
+#endif
   if (act1) {
     float* dst = my + g1 * MAP_LDS + c;
     dcts::static_for<HP>([&](auto i) DCTS_LAMBDA_INLINE {
