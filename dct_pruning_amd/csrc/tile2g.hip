@@ -20,7 +20,9 @@
 // LDS traffic: 2 writes + 2 reads per point; workgroup barriers: 4 per G maps (2 where all 4^L blocks of the
 // G maps fit the LDS at once). With L = 3 the blocks go through LDS in two sets, the second set's 32 values
 // per lane parked in the producer's registers meanwhile (as in tile2d.hip); the next round's samples land in
-// the registers a set has just vacated, trickled out between the codelets.
+// the registers a set has just vacated, trickled out between the codelets. L = 2 (72, 80: 16 samples per lane, 64 VGPRs,
+// one set) runs TWO workgroups per CU. The loads are single-dword gathers, so a tensor needs no 16-byte alignment, and the
+// cv2 path's odd front pad (71 / 79 / 143 / 159 -> 72 / 80 / 144 / 160) is the PAD instantiation of the same kernel.
 //
 // As in the split family the last add/sub layer of every DCT-IV node above the leaves is folded into the
 // reduction ((a+b)^2 + (a-b)^2 = 2a^2 + 2b^2, SplitNode::wt): energy-path-only shortcut;
@@ -129,7 +131,6 @@ struct G2Cfg {
 #else
   static constexpr bool PAIR = (DCTS_G2_PAIR != 0);
 #endif
-  static constexpr int HOOKS = 3 * PPW;                         // load hook points per set
 };
 
 // Which set a block is in, its position in the set and the order of the passes: blocks sorted by the cost of
