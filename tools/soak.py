@@ -18,11 +18,16 @@ for it in range(iters):
     edge, algo, hi = [(224, dpa.ALGO_PIPE, 1500), (128, dpa.ALGO_PIPE, 4000), (7, dpa.ALGO_LANE, 300000),
                       (9, dpa.ALGO_LANE, 200000), (224, dpa.ALGO_FUSED, 1500), (256, dpa.ALGO_FUSED, 1200), (288, dpa.ALGO_FUSED, 900),
                       (320, dpa.ALGO_FUSED, 700), (224, dpa.ALGO_TILE2D, 3000), (224, dpa.ALGO_TILE2D, 700),
-                      (56, dpa.ALGO_AUTO, 60000), (28, dpa.ALGO_AUTO, 200000), (14, dpa.ALGO_AUTO, 600000)][it % 13]
+                      (56, dpa.ALGO_AUTO, 60000), (28, dpa.ALGO_AUTO, 200000), (14, dpa.ALGO_AUTO, 600000),
+                      # round 3: several maps per round (tile2g.hip), incl. the two-workgroups-per-CU shapes and the odd pad
+                      (72, dpa.ALGO_TILE2D, 20000), (80, dpa.ALGO_TILE2D, 15000), (144, dpa.ALGO_TILE2D, 6000),
+                      (160, dpa.ALGO_TILE2D, 4000), (128, dpa.ALGO_TILE2D, 6000), (112, dpa.ALGO_TILE2D, 8000),
+                      (71, dpa.ALGO_AUTO, 20000), (143, dpa.ALGO_AUTO, 6000), (60, dpa.ALGO_AUTO, 40000), (48, dpa.ALGO_AUTO, 60000)][it % 23]
     nmaps = int(rng.integers(1, hi))
+    pad = edge % 2 == 1 and edge > 9
     x = torch.relu(torch.randn(1, nmaps, edge, edge, device="cuda"))
-    a = dpa.energy_nc(x, algo=algo)
-    b = dpa.energy_nc(x, algo=algo)
+    a = dpa.energy_nc(x, algo=algo, pad_front_if_odd=pad)
+    b = dpa.energy_nc(x, algo=algo, pad_front_if_odd=pad)
     ref = (x.double() ** 2).sum(dim=(-2, -1))
     rel = ((a.double() - ref).abs() / ref.clamp_min(1e-30)).max().item()
     if not torch.equal(a, b) or not rel <= 1e-5:
