@@ -550,3 +550,19 @@ def test_large_tile_with_a_4_byte_aligned_base(n):
     assert rel_err(dpa.energy_nc(x.cuda()).cpu(), got) <= 1e-5
     if n == 72:
         assert torch.equal(dpa.energy_nc(x.cuda()).cpu(), got)  # the same kernel, aligned or not
+
+
+def test_published_jpeg_worked_example_on_gpu():
+    """The published 8x8 worked example of the JPEG literature (tests/golden/jpeg_example_8x8.json: data typed from the
+    publication) through the product's coefficient path, codelet and direct kernels: a known answer that comes from
+    neither SciPy, the oracle nor the reference."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_example_8x8.json")))
+    x = (torch.tensor(g["block"], dtype=torch.float32) + g["level_shift"])[None, None]
+    want = np.array(g["published_dct_rows_0_to_2"])
+    for algo in (dpa.ALGO_AUTO, dpa.ALGO_CODELET, dpa.ALGO_DIRECT):
+        got = dpa.dct2d(x.cuda(), algo=algo).cpu().numpy()[0, 0]
+        assert np.abs(got[:3] - want).max() <= g["published_precision"] + 1e-3, algo
+        e = dpa.energy_nc(x.cuda(), algo=algo).item()
+        assert abs(e - float((x.double() ** 2).sum())) <= 1e-5 * e

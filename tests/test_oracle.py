@@ -119,3 +119,23 @@ def test_select_index_rule():
     imp = np.array([3., 0., 5., 0., 1., 4.], dtype=np.float32)
     np.testing.assert_array_equal(orc.select_index(imp, 6, 3), [0, 2, 5])
     assert orc.kept_filters(64, 0.5) == 32 and orc.kept_filters(512, 0.95) == 25
+
+
+def test_published_jpeg_worked_example():
+    """A vector that neither SciPy nor this repo produced: the 8x8 block of the JPEG literature's worked example and its
+    forward DCT as published (to two decimals). The JPEG FDCT is the orthonormal 2-D DCT-II of the level-shifted samples,
+    i.e. what torch_dct.dct_2d(norm='ortho') / cv2.dct compute at utils/common.py:267 / :237. It pins the oracle's
+    transform DEFINITION and normalisation against a published result (to the publication's 5e-3, ~1e-5 of the DC term);
+    the round-off of torch_dct / cv2 themselves stays unpinned (neither is installable here)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_example_8x8.json")))
+    x = torch.tensor(g["block"], dtype=torch.float32) + g["level_shift"]
+    want = np.array(g["published_dct_rows_0_to_2"])
+    tol = g["published_precision"] + 1e-3
+    for got in (orc.dct_2d(x).numpy(), orc.dct_2d_f64(x.numpy()[None])[0], orc.torch2dct(x).numpy()):
+        assert np.abs(got[:3] - want).max() <= tol
+    # the score of that map (Parseval: sum of the level-shifted samples squared) through every oracle entry point
+    e = float((x.double() ** 2).sum())
+    assert abs(float(orc.energy_nc(x[None, None])[0, 0]) - e) <= 1e-5 * e
+    assert abs(float(orc.energy_nc_batched(x[None, None])[0, 0]) - e) <= 1e-5 * e
