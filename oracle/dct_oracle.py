@@ -24,6 +24,9 @@ published algorithm is restated here:
 PARITY PINNING. The reference ships no test, golden vector or fixture for this path
  and the two DCT packages are absent, so parity with their exact
 round-off is UNPINNED. What pins this oracle instead:
+  * the worked 8x8 example of the JPEG literature (block and forward DCT as published, two decimals;
+    tests/golden/jpeg_example_8x8.json): the transform's definition and normalisation, from a source that is
+    neither SciPy, this repo nor the reference (tests/test_oracle.py::test_published_jpeg_worked_example);
   * scipy.fft.dctn(type=2, norm='ortho') in float64 — the same mathematical transform
     (tests/test_oracle.py), agreement <= 2e-7 of the coefficient scale;
   * Parseval: sum(coeff^2) == sum(x^2) for the orthonormal transform;
