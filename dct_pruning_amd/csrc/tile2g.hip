@@ -235,6 +235,18 @@ __device__ const G2ParamTable<L, M, NSETS> kG2Params = g2_make_params<L, M, NSET
 template <int M, int PB, int LW>
 __device__ const G2LaneMap kG2Lanes{M, PB, LW};
 
+// Per-map sums: every lane leaves its sum in LDS and wave 0 adds the sixteen waves' values per lane (fixed order) and runs ONE
+// segmented reduction over the rows of a block after the next barrier - instead of a five-step shuffle reduction in each of the
+// sixteen waves at the end of every round. Same box, % of the HBM peak: 72 x 72 38.7 -> 41.9 (5760 maps), 49.6 -> 51-52 (32768);
+// 80: 41.7 -> 43.4; 144: 41.5 -> 42.4 (4992), 41 -> 43-44 (8192); 160: 39.8 -> 40.2. Bit-reproducible either way.
+#ifndef DCTS_G2_LATE_REDUCE
+#define DCTS_G2_LATE_REDUCE 1
+#endif
+// Waves without items skip the network and set-store phases, and the last of them takes the per-map sums: same box,
+// 160: 39.5 -> 40.4 %, 80: 42.9 -> 43.6 %, 112: 35.5 -> 36.0 % of the HBM peak (144 / 72 have items on every wave: unchanged path).
+#ifndef DCTS_G2_SKIP_IDLE
+#define DCTS_G2_SKIP_IDLE 1
+#endif
 #ifndef DCTS_G2_SKEW
 #define DCTS_G2_SKEW 0
 #endif
@@ -577,6 +589,29 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
   int pending_count = 0, pslot = 0, pending_slot = 0;
   auto finish = [&]() DCTS_LAMBDA_INLINE {
     if (pending >= 0) {
+#if DCTS_G2_LATE_REDUCE
+      // ONE wave - the last, which holds the fewest items or none: per lane the sixteen waves' sums in fixed order, then ONE
+      // segmented reduction over the rows of a block
+      // (wave 0 where every wave has items: 144 / 72 lose 2-3 % with the duty on a wave that also has a full share of items)
+      if (wave == ((DCTS_G2_SKIP_IDLE && Cfg::ITEMS <= (NW - 1) * 64) ? NW - 1 : 0)) {
+        const int mb = launder(map_b);
+        const int j = (mb >> 8) & 0xff;
+        const bool act = (mb >> 16) != 0;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) t += partials[(pending_slot * NW + i) * 64 + launder(lane_in)];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          if (off < M) {
+            const float u = __shfl_down(t, off, 64);
+            if (act && j + off < M) t += u;
+          }
+        }
+        constexpr float sc = float(4.0 / (double(N) * double(N)));
+        if constexpr (!STORE)
+          if (act && j == 0 && (mb & 0xff) < pending_count) pending_out[mb & 0xff] = t * sc;
+      }
+#else
       if (wave == 0 && lane_in < pending_count) {
         float t = 0.f;
 #pragma unroll
@@ -584,6 +619,7 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
         constexpr float sc = float(4.0 / (double(N) * double(N)));
         if constexpr (!STORE) pending_out[lane_in] = t * sc;
       }
+#endif
       pending = -1;
     }
   };
@@ -591,7 +627,9 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
   G2_STAMP(15);
   for (; grp < ngroups; grp += gridDim.x) {
     // ---- A: role networks of this lane's item, both axes, in registers -----------------------------------
-    {
+    // (G * M * M items on 1024 lanes: the last waves may hold none at all - 800 items at 160 and 80, 784 at 112 - and skip
+    // the networks and the stores of the sets: wave-uniform, and three waves fewer compete for the VALUs and the LDS there)
+    if (DCTS_G2_SKIP_IDLE == 0 || wave * 64 < Cfg::ITEMS) {
       const int p = launder(ip), q = launder(iq);
       float rp[NROT > 0 ? NROT : 1][4];
       dcts::static_for<NROT>([&](auto ir_) DCTS_LAMBDA_INLINE {
@@ -641,7 +679,7 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
     dcts::static_for<NSETS>([&](auto iset) DCTS_LAMBDA_INLINE {
       constexpr int SET = decltype(iset)::value;
       // ---- this set's leaf-block samples -> LDS ------------------------------------------------------------
-      {
+      if (DCTS_G2_SKIP_IDLE == 0 || wave * 64 < Cfg::ITEMS) {
         const int p = launder(ip), q = launder(iq), g = launder(ig);
         const int dump = NBS * G * BS + (launder(lane_in) & 3);  // lanes without an item store behind the set
         const int gofs = g * BS;
@@ -701,6 +739,9 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
       }
     });
     // ---- per-map sums: over the rows of a block (lanes of a group), then over the waves ---------------------
+#if DCTS_G2_LATE_REDUCE
+    partials[(pslot * NW + wave) * 64 + launder(lane_in)] = e_acc;  // lanes outside a block hold 0; summed by wave 0 (finish)
+#else
     {
       const int mb = launder(map_b);
       const int j = (mb >> 8) & 0xff;
@@ -715,6 +756,7 @@ __device__ __forceinline__ void g2_body(const G2Batch& gb, lds_ptr zbuf, lds_ptr
       }
       if (act && j == 0) partials[(pslot * NW + wave) * G + (mb & 0xff)] = e;
     }
+#endif
     pending = grp;
     pending_out = cur.out;
     pending_count = cur.count;
@@ -748,7 +790,7 @@ __global__ __launch_bounds__((64 * kG2Waves), (4 * g2_wgs_per_cu<L, M, G>())) vo
   __shared__ __attribute__((aligned(16))) float zbuf[Cfg::ZSET];
   __shared__ __attribute__((aligned(16))) float rot[(Cfg::NROT > 0 ? Cfg::NROT : 1) * M * 4];
   __shared__ __attribute__((aligned(16))) float params[Cfg::NSETS * Cfg::NBS * 8];
-  __shared__ float partials[2 * kG2Waves * G];
+  __shared__ float partials[2 * kG2Waves * (DCTS_G2_LATE_REDUCE ? 64 : G)];
   g2_body<L, M, G, STORE, PAD>(gb, (lds_ptr)zbuf, (lds_ptr)rot, (lds_ptr)params, (lds_ptr)partials, leaf_out);
 }
 
