@@ -16,6 +16,7 @@ from .ops import (  # noqa: F401
     ALGO_PREFETCH,
     ALGO_SPLIT,
     ALGO_TILE2D,
+    ALGO_RECT,
     batch_sum,
     dct2d,
     energy_mixed,
@@ -25,4 +26,4 @@ from .ops import (  # noqa: F401
     weighted_energy_nc,
 )
 
-__all__ = ["energy_nc", "energy_multi", "energy_mixed", "dct2d", "batch_sum", "has_codelet", "weighted_energy_nc", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE", "ALGO_TILE2D"]
+__all__ = ["energy_nc", "energy_multi", "energy_mixed", "dct2d", "batch_sum", "has_codelet", "weighted_energy_nc", "ALGO_AUTO", "ALGO_DIRECT", "ALGO_CODELET", "ALGO_SPLIT", "ALGO_PREFETCH", "ALGO_FUSED", "ALGO_PIPE", "ALGO_LANE", "ALGO_TILE2D", "ALGO_RECT"]

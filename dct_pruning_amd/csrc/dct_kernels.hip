@@ -31,6 +31,7 @@
 #include "codelet_sizes.h"
 #include "dct_codelets.hpp"
 #include "split_roles.hpp"
+#include "rect.h"
 
 // The file is compiled six times in parallel (Makefile: -DDCTS_TU=1..6), each translation unit
 // instantiating one kernel family; DCTS_TU=0 (default) builds everything in one unit. Only the
@@ -2606,9 +2607,30 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
   const bool codelet_ok = has_codelet(HP, WP) && strideH == W;
   if ((algo == DCTS_ALGO_CODELET || algo == DCTS_ALGO_PREFETCH) && !codelet_ok) return DCTS_E_UNSUPPORTED;
   if (algo != DCTS_ALGO_AUTO && algo != DCTS_ALGO_DIRECT && algo != DCTS_ALGO_CODELET &&
-      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED && algo != DCTS_ALGO_PIPE && algo != DCTS_ALGO_LANE && algo != DCTS_ALGO_TILE2D)
+      algo != DCTS_ALGO_SPLIT && algo != DCTS_ALGO_PREFETCH && algo != DCTS_ALGO_FUSED && algo != DCTS_ALGO_PIPE && algo != DCTS_ALGO_LANE && algo != DCTS_ALGO_TILE2D && algo != DCTS_ALGO_RECT)
     return DCTS_E_UNSUPPORTED;
   if (algo == DCTS_ALGO_LANE && !(codelet_ok && !STORE && pad == 0 && has_lane_kernel((int)HP))) return DCTS_E_UNSUPPORTED;
+  // both edges have a 1-D codelet, but the maps are not square or their rows not dense: the run-time pair of codelets
+  // (rect.hip). Square dense maps keep their own kernels unless ALGO_RECT asks (tests compare the two).
+  const bool rect_ok = HP <= 64 && WP <= 64 && dctsi::has_rect((int)HP, (int)WP) != 0;
+  if (algo == DCTS_ALGO_RECT && !rect_ok) return DCTS_E_UNSUPPORTED;
+  if (rect_ok && (algo == DCTS_ALGO_RECT || (algo == DCTS_ALGO_AUTO && !codelet_ok))) {
+    dctsi::RectGeom r{};
+    r.x = x;
+    r.nmaps = g.nmaps;
+    r.strideN = strideN;
+    r.strideC = strideC;
+    r.strideH = strideH;
+    r.c_count = c_count;
+    r.c_begin = c_begin;
+    r.H = (int)H;
+    r.W = (int)W;
+    r.HP = (int)HP;
+    r.WP = (int)WP;
+    r.pad = pad;
+    r.contiguous = g.contiguous;
+    return dctsi::dispatch_rect(r, out, STORE ? 1 : 0, st);
+  }
   if (codelet_ok && algo != DCTS_ALGO_DIRECT) {
     if constexpr (!STORE) {
       if ((algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_LANE) && pad == 0 && has_lane_kernel((int)HP)) {

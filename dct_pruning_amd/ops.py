@@ -4,7 +4,7 @@ import torch
 
 from . import _lib
 
-ALGO_AUTO, ALGO_DIRECT, ALGO_CODELET, ALGO_SPLIT, ALGO_PREFETCH, ALGO_FUSED, ALGO_PIPE, ALGO_LANE, ALGO_TILE2D = 0, 1, 2, 3, 4, 5, 6, 7, 8
+ALGO_AUTO, ALGO_DIRECT, ALGO_CODELET, ALGO_SPLIT, ALGO_PREFETCH, ALGO_FUSED, ALGO_PIPE, ALGO_LANE, ALGO_TILE2D, ALGO_RECT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 # one scratch buffer per (device, stream); grown on demand, reused across calls
 _workspaces = {}

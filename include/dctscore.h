@@ -72,9 +72,12 @@ enum {
   DCTS_ALGO_PIPE = 6,     /* the fused kernel software-pipelined: pass 2 of one map interleaved
                              with pass 1 of the next                                             */
   DCTS_ALGO_LANE = 7,     /* one lane per map, both passes in registers (7x7, 9x9)              */
-  DCTS_ALGO_TILE2D = 8    /* 2-D radix split: butterflies over both axes in registers, then 4^L independent
+  DCTS_ALGO_TILE2D = 8,   /* 2-D radix split: butterflies over both axes in registers, then 4^L independent
                              M x M leaf blocks - 224 (tile2d.hip); 72, 80, 112, 128, 144, 160 with several maps
                              per round (tile2g.hip)                                              */
+  DCTS_ALGO_RECT = 9      /* the 1-D codelets picked per axis at run time: any (H, W) whose two edges (after the
+                             odd pad) are codelet sizes - non-square maps, rows with strideH > W (rect.hip);
+                             what AUTO takes for such shapes                                      */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */
@@ -94,7 +97,11 @@ size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W);
  * torch2dct, :230-239, when pad_front_if_odd != 0).
  *
  *   x            fp32 feature maps, logical shape [N, C_total, H, W]; element (n,c,h,w) is at
- *                x[n*strideN + c*strideC + h*strideH + w*strideW]; strideW must be 1.
+ *                x[n*strideN + c*strideC + h*strideH + w*strideW]; strideW must be 1, strideH >= W.
+ *                Any (H, W) <= DCTS_MAX_EDGE is accepted; which kernel runs depends on the shape: square
+ *                dense maps of the tabulated edges have their own kernels, non-square maps and maps with
+ *                strideH > W whose edges are codelet sizes (<= 64) the run-time codelet pair
+ *                (DCTS_ALGO_RECT), everything else the cosine-matrix kernel (DCTS_ALGO_DIRECT).
  *   c_begin,
  *   c_count      channel slice to score (densenet hook: c_begin = C_total-12, c_count = 12).
  *   pad_front_if_odd

@@ -213,6 +213,70 @@ def test_non_square_direct(hw):
     check(x, dpa.energy_nc(x.cuda()))
 
 
+RECT = [(56, 28), (28, 56), (14, 20), (20, 14), (7, 10), (64, 2), (2, 64), (9, 18), (32, 16), (60, 36), (48, 64), (8, 8), (56, 56), (7, 7)]
+
+
+@pytest.mark.parametrize("hw", RECT)
+def test_rect_codelet_pairs(hw):
+    """Non-square maps whose two edges are codelet sizes: one kernel, the two 1-D codelets picked at run time
+    (rect.hip). Energy against the oracle, AUTO = this kernel for non-square shapes, bit-reproducible over a launch with many
+    groups per wave and a ragged tail, coefficients against float64."""
+    h, w = hw
+    x = synth(3, 19, h, w, 100 + 3 * h + w)
+    got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_RECT)
+    check(x, got)
+    ref = orc.energy_nc(x[:1, :4])  # the reference's per-map loop
+    assert rel_err(got[:1, :4].cpu(), ref) <= RTOL
+    auto = dpa.energy_nc(x.cuda())
+    if h != w:
+        assert torch.equal(auto, got)
+    else:  # square maps keep their own kernels; the same codelets in the same order
+        assert rel_err(auto.cpu(), got.cpu()) <= 1e-5
+    big = synth(5, 1201, h, w, 7 + h, dead=True).cuda()
+    b = dpa.energy_nc(big, algo=dpa.ALGO_RECT)
+    check(big.cpu(), b)
+    assert torch.equal(b, dpa.energy_nc(big, algo=dpa.ALGO_RECT))
+    xs = synth(2, 3, h, w, 9 + w, dead=False)
+    co = dpa.dct2d(xs.cuda(), algo=dpa.ALGO_RECT).cpu().numpy()
+    cref = orc.dct_2d_f64(xs.numpy())
+    assert co.shape == cref.shape and np.abs(co - cref).max() <= 2e-6 * np.abs(cref).max()
+
+
+@pytest.mark.parametrize("hw", [(56, 56), (28, 14), (14, 14), (9, 18), (36, 60)])
+def test_rows_that_are_not_dense(hw):
+    """A spatial crop of a wider tensor: strideH > W, 4-byte-aligned rows. Handed to the library as it is (no copy): equal,
+    bit for bit, to the same kernel on a dense copy."""
+    h, w = hw
+    base = synth(2, 11, h + 5, w + 7, 300 + h).cuda()
+    view = base[:, :, 2:2 + h, 3:3 + w]
+    assert view.stride(2) == w + 7 and not view.is_contiguous()
+    got = dpa.energy_nc(view)
+    check(view.cpu().contiguous(), got)
+    assert torch.equal(got, dpa.energy_nc(view.contiguous(), algo=dpa.ALGO_RECT))
+    sl = dpa.energy_nc(view, c_begin=3, c_count=5)
+    assert torch.equal(sl, got[:, 3:8])
+
+
+@pytest.mark.parametrize("hw", [(7, 9), (9, 7), (13, 19), (55, 27), (63, 63)])
+def test_rect_odd_front_pad(hw):
+    """cv2 path on a non-square odd-H map: one zero row and one zero column in front (np.pad(t, (1, 0)), utils/common.py:235-236)."""
+    h, w = hw
+    x = synth(2, 9, h, w, 500 + h)
+    got = dpa.energy_nc(x.cuda(), pad_front_if_odd=True, algo=dpa.ALGO_RECT)
+    check(x, got, pad_front_if_odd=True)
+    assert torch.equal(got, dpa.energy_nc(x.cuda(), pad_front_if_odd=True)) or h == w
+    co = dpa.dct2d(x[:1, :2].cuda(), pad_front_if_odd=True, algo=dpa.ALGO_RECT).cpu().numpy()
+    cref = orc.dct_2d_f64(np.pad(x[:1, :2].numpy(), ((0, 0), (0, 0), (1, 0), (1, 0))))
+    assert co.shape == cref.shape and np.abs(co - cref).max() <= 2e-6 * np.abs(cref).max()
+
+
+def test_rect_is_refused_where_an_edge_has_no_codelet():
+    x = synth(1, 2, 22, 14, 1).cuda()
+    with pytest.raises(Exception):
+        dpa.energy_nc(x, algo=dpa.ALGO_RECT)
+    check(x.cpu(), dpa.energy_nc(x))  # AUTO: the cosine-matrix kernel
+
+
 @pytest.mark.parametrize("n", [7, 9, 13, 15, 17, 19, 27, 31, 35, 39, 55, 63, 71])
 def test_odd_front_pad(n):
     """cv2 path (torch2dct): odd H -> one zero row and column in front."""
