@@ -33,7 +33,7 @@
 #include "split_roles.hpp"
 #include "rect.h"
 
-// The file is compiled six times in parallel (Makefile: -DDCTS_TU=1..6), each translation unit
+// The file is compiled seven times in parallel (Makefile: -DDCTS_TU=1..7), each translation unit
 // instantiating one kernel family; DCTS_TU=0 (default) builds everything in one unit. Only the
 // dispatchers that instantiate kernels cross units: they are declared here with the geometry
 // structs passed as opaque pointers (the structs live in the anonymous namespace of every unit).
@@ -52,7 +52,7 @@
 #ifndef DCTS_FUSED2_AUTO
 #define DCTS_FUSED2_AUTO 1  // AUTO uses the two-roles-per-wave fused kernel where it exists (288: 31 % vs 18 %, 320: 31 % vs 17 % of the HBM peak)
 #endif
-#define DCTS_PART(n) (DCTS_TU == 0 || DCTS_TU == (n))  // 1 codelet+lane, 2 two-launch split, 3 fused, 4 pipelined, 5 rest + C ABI, 6 fused with two roles per wave
+#define DCTS_PART(n) (DCTS_TU == 0 || DCTS_TU == (n))  // 1 codelet+lane, 2 two-launch split, 3 fused, 4 pipelined, 5 rest + C ABI, 6 fused with two roles per wave, 7 two-launch split: the 8 * M edges of round 3
 namespace dctsi {
 int dispatch_codelet(int store, int HP, int WP, int pad, const void* geom, float* out, hipStream_t st);
 int dispatch_codelet_dma(int N, const void* geom, float* out, hipStream_t st);
@@ -60,6 +60,7 @@ int dispatch_codelet_multi(int HP, int pad, const void* multi_geom, hipStream_t 
 int dispatch_lane(int n, const void* multi_geom, hipStream_t st);
 int dispatch_codelet_mixed(const void* mixed_geom, hipStream_t st);
 int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStream_t st);
+int dispatch_split_more(int N, const void* geom, float* out, void* workspace, hipStream_t st);  // the 8 * M entries added in round 3 (DCTS_TU=7)
 int dispatch_fused(int N, const void* tile_batch, hipStream_t st);
 int dispatch_fused2(int N, const void* tile_batch, hipStream_t st);
 int dispatch_pipe(int N, const void* tile_batch, hipStream_t st);
@@ -2068,9 +2069,24 @@ inline int dispatch_codelet(int HP, int WP, int pad, const MapGeom& g, float* ou
 // tile edges served by the split family: X(N, M, L) with N = M << L. L = 3 (eight M-point roles)
 // where the four-role codelets would be too register-hungry for more than 1-2 waves per SIMD.
 #ifndef DCTS_SPLIT_TABLE
-#define DCTS_SPLIT_TABLE(X)                                                              \
+// Round 3: the other multiples of 4 up to 256 (N = 4 * M) and of 8 up to 512 (N = 8 * M) with M <= 64 even or M <= 32 - the
+// codelet template factorises any M; an odd M beyond 32 would be a direct M x M sum per leaf: minutes of build time each and
+// compute-bound. These edges (an --input_size such as 272 / 304 / 352 / 384 / 448 / 512 and their halves) have no single-launch
+// kernel: they take the two-launch path (3 x the algorithmic traffic: <= 0.2 of the HBM peak) instead of the cosine-matrix kernel
+// (< 0.01). The 8 * M entries are a translation unit of their own (DCTS_TU=7).
+#define DCTS_SPLIT_TABLE_MORE_A(X) \
+  X(68, 17, 2) X(76, 19, 2) X(84, 21, 2) X(88, 22, 2) X(92, 23, 2) X(100, 25, 2) X(104, 26, 2) \
+  X(108, 27, 2) X(116, 29, 2) X(120, 30, 2) X(124, 31, 2) X(136, 34, 2) X(152, 38, 2) X(168, 42, 2) \
+  X(176, 44, 2) X(184, 46, 2) X(200, 50, 2) X(208, 52, 2) X(216, 54, 2) X(232, 58, 2) X(240, 60, 2) \
+  X(248, 62, 2)
+#define DCTS_SPLIT_TABLE_MORE_B(X) \
+  X(272, 34, 3) X(304, 38, 3) X(336, 42, 3) X(352, 44, 3) X(368, 46, 3) X(384, 48, 3) X(400, 50, 3) \
+  X(416, 52, 3) X(432, 54, 3) X(448, 56, 3) X(464, 58, 3) X(480, 60, 3) X(496, 62, 3) X(512, 64, 3)
+#define DCTS_SPLIT_TABLE_MORE(X) DCTS_SPLIT_TABLE_MORE_A(X) DCTS_SPLIT_TABLE_MORE_B(X)
+#define DCTS_SPLIT_TABLE_BASE(X)                                                         \
   X(72, 18, 2) X(80, 20, 2) X(96, 24, 2) X(112, 28, 2) X(128, 32, 2) X(144, 36, 2) X(160, 40, 2)      \
   X(192, 24, 3) X(224, 28, 3) X(256, 32, 3) X(288, 36, 3) X(320, 40, 3)
+#define DCTS_SPLIT_TABLE(X) DCTS_SPLIT_TABLE_BASE(X) DCTS_SPLIT_TABLE_MORE(X)
 #endif
 
 bool has_split(long long HP, long long WP) {
@@ -2350,7 +2366,30 @@ int dispatch_split(int N, const void* geom, float* out, void* workspace, hipStre
   case N_:                    \
     return launch_split<M_, L_>(g, out, workspace, st);
   switch (N) {
+#ifdef DCTS_SPLIT_TABLE_MORE_A
+    DCTS_SPLIT_TABLE_BASE(DCTS_CASE)
+    DCTS_SPLIT_TABLE_MORE_A(DCTS_CASE)
+    default:
+      return dispatch_split_more(N, geom, out, workspace, st);
+#else
     DCTS_SPLIT_TABLE(DCTS_CASE)
+    default:
+      return DCTS_E_UNSUPPORTED;
+#endif
+  }
+#undef DCTS_CASE
+}
+}  // namespace dctsi
+#endif
+#if DCTS_PART(7) && defined(DCTS_SPLIT_TABLE_MORE_B)
+namespace dctsi {
+int dispatch_split_more(int N, const void* geom, float* out, void* workspace, hipStream_t st) {
+  const MapGeom& g = *static_cast<const MapGeom*>(geom);
+#define DCTS_CASE(N_, M_, L_) \
+  case N_:                    \
+    return launch_split<M_, L_>(g, out, workspace, st);
+  switch (N) {
+    DCTS_SPLIT_TABLE_MORE_B(DCTS_CASE)
     default:
       return DCTS_E_UNSUPPORTED;
   }

@@ -26,6 +26,15 @@
 
 #include "rect.h"
 
+// every edge up to 64: the codelet template factorises any N = 2^s * m (m odd: direct, about m^2 / 2 FMAs with literal
+// constants), so edges without a square kernel of their own (3, 5, 11, 13, 15, 22, 26, 34 ...) are served here too
+#ifdef DCTS_DEV_FAST
+#define DCTS_RECT_SIZES(X) DCTS_CODELET_SIZES(X)
+#else
+#define DCTS_RECT_SIZES(X) \
+  X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
+#endif
+
 namespace {
 
 using dctsi::RectGeom;
@@ -79,7 +88,9 @@ __device__ __forceinline__ float rect_rows(const float* src, float* o, float sc,
 
 // MAXE: the longest edge this instantiation serves (16 / 32 / 64): its register count is that of the MAXE-point codelet, so
 // small tiles keep the occupancy their HBM-latency-bound loops need (64: 151 VGPRs, 3 waves per SIMD for every shape)
-template <bool STORE, int MAXE, bool ONESTEP>
+// ALL: every edge 1 ... 64 (the odd-length direct codelets need more registers: 209 instead of 151 in the 64 class), else the
+// tabulated codelet sizes only
+template <bool STORE, int MAXE, bool ONESTEP, bool ALL>
 __global__ __launch_bounds__(64 * kRectWaves) void k_energy_rect(RectGeom g, float* __restrict__ out) {
   extern __shared__ float rect_slab[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -105,13 +116,20 @@ __global__ __launch_bounds__(64 * kRectWaves) void k_energy_rect(RectGeom g, flo
       const bool data_col = has && c >= pad;
       const float* p = rect_map_base(g, has ? m1 : g.nmaps - 1) + (data_col ? c - pad : 0);
       float* dst = my + (a1 ? gi : 0) * g.map_lds + (a1 ? c : 0);
-      switch (HP) {
 #define DCTS_CASE(N) \
   case N: if constexpr (N <= MAXE) rect_cols<N>(p, g.strideH, pad, !data_col, dst, S, a1); break;
-        DCTS_CODELET_SIZES(DCTS_CASE)
-#undef DCTS_CASE
-        default: break;
+      if constexpr (ALL) {
+        switch (HP) {
+          DCTS_RECT_SIZES(DCTS_CASE)
+          default: break;
+        }
+      } else {
+        switch (HP) {
+          DCTS_CODELET_SIZES(DCTS_CASE)
+          default: break;
+        }
       }
+#undef DCTS_CASE
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -125,13 +143,20 @@ __global__ __launch_bounds__(64 * kRectWaves) void k_energy_rect(RectGeom g, flo
       const float* src = my + (a2 ? gi : 0) * g.map_lds + (a2 ? k : 0) * S;
       float* o = STORE ? out + ((ok2 ? m2 : 0) * HP + k) * WP : nullptr;
       float e = 0.f;
-      switch (WP) {
 #define DCTS_CASE(N) \
   case N: if constexpr (N <= MAXE) e = rect_rows<N, STORE>(src, o, scale_c, ok2); break;
-        DCTS_CODELET_SIZES(DCTS_CASE)
-#undef DCTS_CASE
-        default: break;
+      if constexpr (ALL) {
+        switch (WP) {
+          DCTS_RECT_SIZES(DCTS_CASE)
+          default: break;
+        }
+      } else {
+        switch (WP) {
+          DCTS_CODELET_SIZES(DCTS_CASE)
+          default: break;
+        }
       }
+#undef DCTS_CASE
       if constexpr (!STORE) {
         if (!a2) e = 0.f;
         // segmented sum over the HP lanes of a map (lane k == 0 ends with it): the codelet kernel's order
@@ -161,10 +186,18 @@ int rect_num_cus() {
   return n;
 }
 
-bool rect_has_1d(int n) {
+bool rect_tab_1d(int n) {
 #define DCTS_CASE(N) \
   if (n == N) return true;
   DCTS_CODELET_SIZES(DCTS_CASE)
+#undef DCTS_CASE
+  return false;
+}
+
+bool rect_has_1d(int n) {
+#define DCTS_CASE(N) \
+  if (n == N) return true;
+  DCTS_RECT_SIZES(DCTS_CASE)
 #undef DCTS_CASE
   return false;
 }
@@ -201,6 +234,7 @@ int dispatch_rect(const RectGeom& g_in, float* out, int store_coeff, hipStream_t
   if (g.G1 > g.G) g.G1 = g.G;
   if (g.G2 > g.G) g.G2 = g.G;
   const bool onestep = g.G1 == g.G && g.G2 == g.G;
+  const bool tabulated = rect_tab_1d(g.HP) && rect_tab_1d(g.WP);
   g.scale_e = float(4.0 / (double(g.HP) * double(g.WP)));
   g.scale_c = float(2.0 / dcts::cx_sqrt(double(g.HP) * double(g.WP)));
   const size_t lds = (size_t)kRectWaves * g.G * g.map_lds * sizeof(float);
@@ -210,19 +244,24 @@ int dispatch_rect(const RectGeom& g_in, float* out, int store_coeff, hipStream_t
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   static const bool attr_ok = [] {  // four 64 x 65 slabs are 66.6 KB: above the 64 KB a kernel gets without asking
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<true, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<false, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<true, 64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<false, 64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
+           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<false, 64, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
   }();
   if (!attr_ok) return DCTS_E_UNSUPPORTED;
   const dim3 grid((unsigned)blocks), wg(64 * kRectWaves);
   auto launch = [&](auto maxe) {
     constexpr int E = decltype(maxe)::value;
     if (store_coeff)
-      hipLaunchKernelGGL((k_energy_rect<true, E, true>), grid, wg, lds, st, g, out);  // coefficients: parity path, one step per pass
+      hipLaunchKernelGGL((k_energy_rect<true, E, true, true>), grid, wg, lds, st, g, out);  // coefficients: parity path, one step per pass
+    else if (onestep && tabulated)
+      hipLaunchKernelGGL((k_energy_rect<false, E, true, false>), grid, wg, lds, st, g, out);
     else if (onestep)
-      hipLaunchKernelGGL((k_energy_rect<false, E, true>), grid, wg, lds, st, g, out);
+      hipLaunchKernelGGL((k_energy_rect<false, E, true, true>), grid, wg, lds, st, g, out);
+    else if (tabulated)
+      hipLaunchKernelGGL((k_energy_rect<false, E, false, false>), grid, wg, lds, st, g, out);
     else
-      hipLaunchKernelGGL((k_energy_rect<false, E, false>), grid, wg, lds, st, g, out);
+      hipLaunchKernelGGL((k_energy_rect<false, E, false, true>), grid, wg, lds, st, g, out);
   };
   if (edge <= 16)
     launch(std::integral_constant<int, 16>{});

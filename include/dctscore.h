@@ -64,7 +64,7 @@ enum {
   DCTS_ALGO_AUTO = 0,     /* pick the fastest kernel that supports the shape                     */
   DCTS_ALGO_DIRECT = 1,   /* cosine-basis-in-LDS separable kernel, any (H, W) <= DCTS_MAX_EDGE   */
   DCTS_ALGO_CODELET = 2,  /* register-resident factorised DCT codelets (selected tile sizes)     */
-  DCTS_ALGO_SPLIT = 3,    /* two-launch split-4 codelet passes for edges 4*M (72 ... 320)        */
+  DCTS_ALGO_SPLIT = 3,    /* two-launch split codelet passes for edges 4*M / 8*M (68 ... 512)    */
   DCTS_ALGO_PREFETCH = 4, /* codelet kernel with direct-to-LDS prefetch of the next maps (dense,
                              even-edge square tiles; measured equal to ALGO_CODELET, opt-in)     */
   DCTS_ALGO_FUSED = 5,    /* single-launch split kernel, intermediate tile parked in VGPRs
@@ -75,9 +75,9 @@ enum {
   DCTS_ALGO_TILE2D = 8,   /* 2-D radix split: butterflies over both axes in registers, then 4^L independent
                              M x M leaf blocks - 224 (tile2d.hip); 72, 80, 112, 128, 144, 160 with several maps
                              per round (tile2g.hip)                                              */
-  DCTS_ALGO_RECT = 9      /* the 1-D codelets picked per axis at run time: any (H, W) whose two edges (after the
-                             odd pad) are codelet sizes - non-square maps, rows with strideH > W (rect.hip);
-                             what AUTO takes for such shapes                                      */
+  DCTS_ALGO_RECT = 9      /* the 1-D codelets picked per axis at run time: any (H, W) with both edges (after the
+                             odd pad) <= 64 - non-square maps, odd / prime edges, rows with strideH > W
+                             (rect.hip); what AUTO takes for such shapes                           */
 };
 
 /* ABI version of the loaded library (== DCTS_ABI_VERSION it was built with). */
@@ -100,8 +100,8 @@ size_t dcts_workspace_bytes(int64_t N, int64_t C_count, int64_t H, int64_t W);
  *                x[n*strideN + c*strideC + h*strideH + w*strideW]; strideW must be 1, strideH >= W.
  *                Any (H, W) <= DCTS_MAX_EDGE is accepted; which kernel runs depends on the shape: square
  *                dense maps of the tabulated edges have their own kernels, non-square maps and maps with
- *                strideH > W whose edges are codelet sizes (<= 64) the run-time codelet pair
- *                (DCTS_ALGO_RECT), everything else the cosine-matrix kernel (DCTS_ALGO_DIRECT).
+ *                strideH > W with both edges <= 64 the run-time codelet pair (DCTS_ALGO_RECT: any
+ *                edge 1 ... 64), everything else the cosine-matrix kernel (DCTS_ALGO_DIRECT).
  *   c_begin,
  *   c_count      channel slice to score (densenet hook: c_begin = C_total-12, c_count = 12).
  *   pad_front_if_odd

@@ -29,6 +29,17 @@ def test_dct2_1d(lib, n):
     assert np.abs(out - ref).max() <= 4e-7 * max(np.abs(ref).max(), 1.0) * np.sqrt(n)
 
 
+@pytest.mark.parametrize("n", [n for n in range(1, 65) if n not in SIZES])
+def test_dct2_1d_lengths_without_a_square_kernel(lib, n):
+    """rect.hip instantiates the codelet template for every length up to 64 (odd parts by the direct sum)."""
+    rng = np.random.default_rng(3000 + n)
+    x = rng.standard_normal(n).astype(np.float32)
+    out = np.zeros(n, np.float32)
+    assert lib.codelet_dct2_1d_any(n, x.ctypes.data_as(FP), out.ctypes.data_as(FP)) == 0
+    ref = dct(x.astype(np.float64), type=2) / 2
+    assert np.abs(out - ref).max() <= 4e-7 * max(np.abs(ref).max(), 1.0) * np.sqrt(n)
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_dct4_1d(lib, n):
     rng = np.random.default_rng(1000 + n)

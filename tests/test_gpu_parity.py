@@ -71,15 +71,18 @@ def test_direct_sizes(n):
 
 
 SPLIT = [72, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320]
+# round 3: the other multiples of 4 (<= 256) / 16 (<= 512) whose quarter / eighth is a codelet length: two-launch path only
+SPLIT_MORE = [68, 76, 84, 88, 92, 100, 104, 108, 116, 120, 124, 136, 152, 168, 176, 184, 200, 208, 216, 232, 240, 248,
+              272, 304, 336, 352, 368, 384, 400, 416, 432, 448, 464, 480, 496, 512]
 FUSED = [72, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320]
 TILE2G = [72, 80, 112, 128, 144, 160]   # tile2g.hip: several maps per round (DCTS_ALGO_TILE2D selects it for these edges)
 TILE2G_AUTO = [72, 80, 144, 160]        # ... and AUTO takes it for these
 
 
-@pytest.mark.parametrize("n", SPLIT)
+@pytest.mark.parametrize("n", SPLIT + SPLIT_MORE)
 def test_split_sizes(n):
     """Large tiles: two-launch split-4 codelet passes (N = 4*M)."""
-    x = synth(2, 11, n, n, 30 + n)
+    x = synth(2, 11 if n <= 320 else 5, n, n, 30 + n)
     got = dpa.energy_nc(x.cuda(), algo=dpa.ALGO_SPLIT)
     check(x, got)
     if n not in FUSED:
@@ -270,11 +273,35 @@ def test_rect_odd_front_pad(hw):
     assert co.shape == cref.shape and np.abs(co - cref).max() <= 2e-6 * np.abs(cref).max()
 
 
-def test_rect_is_refused_where_an_edge_has_no_codelet():
-    x = synth(1, 2, 22, 14, 1).cuda()
+def test_rect_is_refused_beyond_64():
+    x = synth(1, 2, 72, 14, 1).cuda()
     with pytest.raises(Exception):
         dpa.energy_nc(x, algo=dpa.ALGO_RECT)
     check(x.cpu(), dpa.energy_nc(x))  # AUTO: the cosine-matrix kernel
+
+
+@pytest.mark.parametrize("n", [n for n in range(1, 65) if n not in CODELET])
+def test_every_edge_up_to_64_has_a_codelet_path(n):
+    """Edges without a square kernel of their own (1, 3, 5, 11, 13, 15, 22, 26 ...: an --input_size such as 160, 176, 208, 240):
+    AUTO = the run-time codelet pair, whose template factorises any length (odd parts by the direct sum)."""
+    x = synth(2, 21, n, n, 700 + n)
+    got = dpa.energy_nc(x.cuda())
+    check(x, got)
+    assert torch.equal(got, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_RECT))
+    assert rel_err(dpa.energy_nc(x.cuda(), algo=dpa.ALGO_DIRECT).cpu(), got.cpu()) <= 1e-5
+    xs = synth(1, 3, n, n, 5 + n, dead=False)
+    co = dpa.dct2d(xs.cuda()).cpu().numpy()
+    cref = orc.dct_2d_f64(xs.numpy())
+    assert np.abs(co - cref).max() <= 2e-6 * np.abs(cref).max()
+
+
+@pytest.mark.parametrize("hw", [(5, 3), (13, 22), (63, 1), (1, 7), (33, 64), (3, 64), (61, 59), (15, 8), (11, 44)])
+def test_rect_odd_and_prime_edges(hw):
+    h, w = hw
+    x = synth(3, 50, h, w, 900 + h + w)
+    got = dpa.energy_nc(x.cuda())
+    check(x, got)
+    assert torch.equal(got, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_RECT))
 
 
 @pytest.mark.parametrize("n", [7, 9, 13, 15, 17, 19, 27, 31, 35, 39, 55, 63, 71])
