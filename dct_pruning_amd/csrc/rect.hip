@@ -243,12 +243,15 @@ int dispatch_rect(const RectGeom& g_in, float* out, int store_coeff, hipStream_t
   const long long cap = (long long)rect_num_cus() * 64;  // a grid several times the residency (dct_kernels.hip, GRID_WAVES_PER_CU)
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  static const bool attr_ok = [] {  // four 64 x 65 slabs are 66.6 KB: above the 64 KB a kernel gets without asking
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<true, 64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<false, 64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess &&
-           hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<false, 64, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+  static const hipError_t attr_rc = [] {  // four 64 x 65 slabs are 66.6 KB: above the 64 KB a kernel gets without asking
+    hipError_t rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<true, 64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<false, 64, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    if (rc == hipSuccess)
+      rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_energy_rect<false, 64, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    return rc;
   }();
-  if (!attr_ok) return DCTS_E_UNSUPPORTED;
+  if (attr_rc != hipSuccess) return (int)attr_rc;  // a HIP error (positive), as for a failed launch
   const dim3 grid((unsigned)blocks), wg(64 * kRectWaves);
   auto launch = [&](auto maxe) {
     constexpr int E = decltype(maxe)::value;
