@@ -1,5 +1,5 @@
 """Seeded differential fuzz of the C ABI against the oracle: random tile shapes (square sizes of every
-kernel family, non-square and odd ones for the direct kernel), batch/channel counts, channel slices,
+kernel family, non-square and odd ones for the run-time codelet pair and the direct kernel), batch/channel counts, channel slices,
 odd front pad, batch-strided and channel-strided views, single and multi-tensor entry points."""
 import numpy as np
 import pytest
@@ -28,7 +28,7 @@ def _case(rng):
     if kind < 7:
         h = w = int(rng.choice(EDGES))
     elif kind < 9:
-        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        h, w = int(rng.integers(1, 65)), int(rng.integers(1, 65))  # any pair up to 64: the run-time codelet pair (rect.hip)
     else:
         h = w = int(rng.integers(65, 130))  # no codelet / split entry for most of these: direct kernel
     big = h * w >= 72 * 72

@@ -22,7 +22,10 @@ for it in range(iters):
                       # round 3: several maps per round (tile2g.hip), incl. the two-workgroups-per-CU shapes and the odd pad
                       (72, dpa.ALGO_TILE2D, 20000), (80, dpa.ALGO_TILE2D, 15000), (144, dpa.ALGO_TILE2D, 6000),
                       (160, dpa.ALGO_TILE2D, 4000), (128, dpa.ALGO_TILE2D, 6000), (112, dpa.ALGO_TILE2D, 8000),
-                      (71, dpa.ALGO_AUTO, 20000), (143, dpa.ALGO_AUTO, 6000), (60, dpa.ALGO_AUTO, 40000), (48, dpa.ALGO_AUTO, 60000)][it % 23]
+                      (71, dpa.ALGO_AUTO, 20000), (143, dpa.ALGO_AUTO, 6000), (60, dpa.ALGO_AUTO, 40000), (48, dpa.ALGO_AUTO, 60000),
+                      # the run-time codelet pair (rect.hip): odd / prime edges, a tabulated edge through it; a two-launch edge of round 3
+                      (13, dpa.ALGO_AUTO, 300000), (22, dpa.ALGO_AUTO, 100000), (63, dpa.ALGO_AUTO, 12000), (28, dpa.ALGO_RECT, 60000),
+                      (176, dpa.ALGO_AUTO, 1500)][it % 28]
     nmaps = int(rng.integers(1, hi))
     pad = edge % 2 == 1 and edge > 9
     x = torch.relu(torch.randn(1, nmaps, edge, edge, device="cuda"))
