@@ -207,9 +207,13 @@ def headline(lib, dev, stream_ptr, ws_fn):
     for name, nmaps, h, nbuf in [("56x56", 16384, 56, 3), ("224x224", 4096, 224, 1), ("28x28", 65536, 28, 3),
                                  ("14x14", 262144, 14, 3), ("7x7", 1048576, 7, 3), ("32x32", 65536, 32, 3),
                                  ("288x288", 2048, 288, 1), ("320x320", 2048, 320, 1), ("144x144", 8192, 144, 1),
-                                 ("72x72", 32768, 72, 1)]:
-        bufs = [synth(1, nmaps, h, h, 777 + i, dev) for i in range(nbuf)]
-        ws = ws_fn(1, nmaps, h, h)
+                                 ("72x72", 32768, 72, 1),
+                                 # round 3: shapes that used to fall to the cosine-matrix kernel - a non-square map and an edge
+                                 # without a square kernel (run-time codelet pair, rect.hip), an edge on the two-launch path only
+                                 ("56x28", 32768, (56, 28), 3), ("13x13", 262144, 13, 3), ("384x384", 512, 384, 1)]:
+        h, w = h if isinstance(h, tuple) else (h, h)
+        bufs = [synth(1, nmaps, h, w, 777 + i, dev) for i in range(nbuf)]
+        ws = ws_fn(1, nmaps, h, w)
         units = [BoundUnit(lib, b, False, stream_ptr, ws) for b in bufs]
         # >= 20 warm-up + >= 100 timed launches, median and min. The length matters for
         # the large tiles: under sustained load the clock management first drops, then raises the shader
