@@ -2530,7 +2530,7 @@ bool has_tile2d(long long N) { return N == 224 || dctsi::has_tile2g((int)N) != 0
 // promises the bits of one call per tensor, whatever the tensors' sizes. So 72, 80, 144, 160 take it, 112 and 128
 // keep the fused / pipelined kernels (DCTS_ALGO_TILE2D still selects it for them).
 bool tile2g_auto(int HP, long long /*nmaps*/) {
-  return dctsi::has_tile2g(HP) && HP != 112 && HP != 128;
+  return dctsi::has_tile2g(HP) && HP != 96 && HP != 112 && HP != 128;
 }
 
 int tile_family(int HP, int algo, long long nmaps) {

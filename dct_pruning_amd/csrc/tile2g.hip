@@ -50,7 +50,8 @@ constexpr int kG2Waves = 16;
 // LDS image of one leaf block: M rows of RS floats, BS floats per block. A pass holds PB blocks, block gl on
 // lanes [gl * LWA, gl * LWA + M) while columns are accessed (axis A) and on [gl * LWB, gl * LWB + M) for
 // rows (axis B); lanes outside repeat the address of the nearest active lane of their 32-lane LDS group
-// (a broadcast). Found by exhaustive search: ds_read/write_b32 conflict-free for every row and column index.
+// (a broadcast). Found by exhaustive search (tools/g2_layout_search.py, which also re-checks the ones below):
+// ds_read/write_b32 conflict-free for every row and column index.
 template <int M, int PB>
 struct G2Layout;
 template <>
@@ -68,6 +69,10 @@ struct G2Layout<14, 4> {
 template <>
 struct G2Layout<20, 2> {
   static constexpr int RS = 21, BS = 420, LWA = 32, LWB = 20;
+};
+template <>
+struct G2Layout<12, 5> {
+  static constexpr int RS = 17, BS = 204, LWA = 12, LWB = 12;
 };
 template <>
 struct G2Layout<20, 3> {
@@ -796,7 +801,7 @@ __global__ __launch_bounds__((64 * kG2Waves), (4 * g2_wgs_per_cu<L, M, G>())) vo
 
 // X(N, L, M, G)
 #ifndef DCTS_TILE2G_TABLE
-#define DCTS_TILE2G_TABLE(X) X(72, 2, 18, 3) X(80, 2, 20, 2) X(112, 3, 14, 4) X(128, 3, 16, 4) X(144, 3, 18, 3) X(160, 3, 20, 2)
+#define DCTS_TILE2G_TABLE(X) X(72, 2, 18, 3) X(80, 2, 20, 2) X(96, 3, 12, 5) X(112, 3, 14, 4) X(128, 3, 16, 4) X(144, 3, 18, 3) X(160, 3, 20, 2)
 #endif
 // ... and with the odd front pad (71, 79, 143, 159 -> 72, 80, 144, 160)
 #ifndef DCTS_TILE2G_PAD_TABLE

@@ -73,7 +73,7 @@ enum {
                              with pass 1 of the next                                             */
   DCTS_ALGO_LANE = 7,     /* one lane per map, both passes in registers (7x7, 9x9)              */
   DCTS_ALGO_TILE2D = 8,   /* 2-D radix split: butterflies over both axes in registers, then 4^L independent
-                             M x M leaf blocks - 224 (tile2d.hip); 72, 80, 112, 128, 144, 160 with several maps
+                             M x M leaf blocks - 224 (tile2d.hip); 72, 80, 96, 112, 128, 144, 160 with several maps
                              per round (tile2g.hip)                                              */
   DCTS_ALGO_RECT = 9      /* the 1-D codelets picked per axis at run time: any (H, W) with both edges (after the
                              odd pad) <= 64 - non-square maps, odd / prime edges, rows with strideH > W

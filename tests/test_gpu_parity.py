@@ -75,7 +75,7 @@ SPLIT = [72, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320]
 SPLIT_MORE = [68, 76, 84, 88, 92, 100, 104, 108, 116, 120, 124, 136, 152, 168, 176, 184, 200, 208, 216, 232, 240, 248,
               272, 304, 336, 352, 368, 384, 400, 416, 432, 448, 464, 480, 496, 512]
 FUSED = [72, 80, 96, 112, 128, 144, 160, 192, 224, 256, 288, 320]
-TILE2G = [72, 80, 112, 128, 144, 160]   # tile2g.hip: several maps per round (DCTS_ALGO_TILE2D selects it for these edges)
+TILE2G = [72, 80, 96, 112, 128, 144, 160]   # tile2g.hip: several maps per round (DCTS_ALGO_TILE2D selects it for these edges)
 TILE2G_AUTO = [72, 80, 144, 160]        # ... and AUTO takes it for these
 
 
