@@ -186,6 +186,9 @@ def kernel_name(edge, per_tensor):
     if edge in (7, 9):
         return "k_energy_lane_multi<%d>" % edge
     if edge <= 64:
+        from dct_pruning_amd import ops
+        if not ops.has_codelet(edge, edge):
+            return "k_energy_rect (%dx%d)" % (edge, edge)  # no square kernel of its own: the run-time codelet pair
         return ("k_energy_codelet<%d,%d>" if per_tensor else "k_energy_codelet_multi<%d,%d>") % (edge, edge)
     if edge == 224:
         return "k_tile2d (224x224)"
@@ -197,6 +200,8 @@ def kernel_name(edge, per_tensor):
         return "k_tile2g (%dx%d)" % (edge, edge)
     if edge in (96, 112, 192, 256):
         return "k_split_fused (%dx%d)" % (edge, edge)
+    if (edge <= 256 and edge % 4 == 0 and ((edge // 4) % 2 == 0 or edge // 4 <= 32)) or (edge <= 512 and edge % 16 == 0):
+        return "k_pass1d x2 (%dx%d, two launches)" % (edge, edge)
     return "k_energy_direct (%dx%d)" % (edge, edge)
 
 
@@ -232,8 +237,19 @@ def headline(lib, dev, stream_ptr, ws_fn):
         ts = sorted(a.elapsed_time(b) for a, b in ev)
         med = ts[len(ts) // 2]
         by = units[0].bytes
+        # the same 100 launches back to back between ONE pair of events: no event packets between the kernels (an event pair
+        # around a 40 us kernel adds ~3.5 us to what it measures, profiles/r03_headline56_launch_series.txt), inter-kernel
+        # gaps included. Reported beside the per-launch median, which stays the headline figure.
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            units[i % nbuf].launch_energy()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ser = e0.elapsed_time(e1) / reps
         out[name] = {"maps": nmaps, "median_us": med * 1e3, "min_us": ts[0] * 1e3,
-                     "Mmaps_s": nmaps / med / 1e3, "GB_s": by / med / 1e6, "frac": by / med / 1e6 / HBM_PEAK_GBS}
+                     "Mmaps_s": nmaps / med / 1e3, "GB_s": by / med / 1e6, "frac": by / med / 1e6 / HBM_PEAK_GBS,
+                     "series_us_per_launch": ser * 1e3, "series_frac": by / ser / 1e6 / HBM_PEAK_GBS}
         del units, bufs
         torch.cuda.empty_cache()
     return out

@@ -513,7 +513,8 @@ def test_lane_per_map_kernel(n):
 
 
 @pytest.mark.parametrize("n,pad", [(8, False), (7, False), (9, False), (9, True), (14, False), (32, False), (56, False), (24, False),
-                                   (72, False), (128, False), (224, False), (288, False)])
+                                   (72, False), (128, False), (224, False), (288, False),
+                                   (13, False), (21, True), (88, False)])  # run-time codelet pair, its odd pad, a two-launch-only edge
 def test_energy_multi_matches_single_calls(n, pad):
     """dcts_energy_multi_f32: many tensors of one tile shape in one launch == one call per tensor
     (bitwise), including channel slices, batch-strided views and more than 32 items (chunking)."""
@@ -535,6 +536,15 @@ def test_energy_multi_matches_single_calls(n, pad):
         ref = dpa.energy_nc(x, c_begin=cb, c_count=cc, pad_front_if_odd=pad)
         assert torch.equal(got, ref)
         check(x.cpu(), got, c_begin=cb, c_count=cc, pad_front_if_odd=pad)
+
+
+def test_energy_multi_with_non_square_maps():
+    """Several non-square tensors through dcts_energy_multi_f32: one call per tensor inside (the run-time codelet pair), same bytes."""
+    base = [synth(2, 6 + i, 28, 14, 880 + i).cuda() for i in range(5)]
+    outs = dpa.energy_multi([(x, 0, None) for x in base])
+    for x, got in zip(base, outs):
+        assert torch.equal(got, dpa.energy_nc(x))
+        check(x.cpu(), got)
 
 
 def test_mixed_shape_launch_is_bitwise_equal_to_per_tensor_calls():
