@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Timing + parity of a development build: tools/devbench.py <lib.so> edge:nmaps:algo ..."""
+"""Timing + parity of a development build: tools/devbench.py <lib.so> edge:nmaps:algo ...
+(DEVBENCH_REPS=100: the headline protocol - 20 warm-up launches, then that many timed ones)"""
 import ctypes
+import os
 import sys
 
 import torch
@@ -26,7 +28,11 @@ for spec in sys.argv[2:]:
     for b in bufs:
         run(b)
     torch.cuda.synchronize()
-    reps = 20
+    reps = int(os.environ.get("DEVBENCH_REPS", "20"))
+    if reps > 20:
+        for i in range(20):
+            run(bufs[i % nbuf])
+        torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for i in range(reps):
         ev[i][0].record()
