@@ -126,3 +126,33 @@ def test_weighted_hook_variant_accumulates_like_the_plain_hook():
     with torch.no_grad():
         want = torch.stack([(conv(b).sum(dim=(-2, -1)) ** 2 / 256.0) for b in batches]).mean(dim=(0, 1))
     assert torch.allclose(dc.cpu(), want.cpu(), rtol=1e-4, atol=1e-6 * float(want.max()))
+
+
+def test_hooks_on_non_square_and_odd_feature_maps_match_the_reference_loop():
+    """A network fed a non-square image (the reference's dct_2d / cv2.dct take any H x W, utils/common.py:267, :237): the three
+    hooks on 48 x 28, 24 x 14 and 13 x 19 (odd H: the cv2 path pads to 14 x 20) feature maps against the oracle's restatement of
+    the reference's per-map loops on the very same activations, running mean over three batches included."""
+    from dct_pruning_amd import harness
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 14, 3, padding=1), torch.nn.ReLU(), torch.nn.MaxPool2d(2),
+                              torch.nn.Conv2d(14, 16, 3, padding=1), torch.nn.ReLU()).cuda().eval()
+    odd = torch.nn.Sequential(torch.nn.Conv2d(3, 13, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(13, 4, 1)).cuda().eval()
+    cases = [(net, net[1], harness.get_feature_hook, lambda st, i, o: orc.get_feature_hook(st, o), (2, 3, 48, 28)),
+             (net, net[4], harness.get_feature_hook_densenet, lambda st, i, o: orc.get_feature_hook_densenet(st, o), (2, 3, 48, 28)),
+             (odd, odd[2], harness.get_feature_hook_u2net_input, lambda st, i, o: orc.get_feature_hook_u2net_input(st, i), (2, 3, 13, 19))]
+    for model, module, hook, ref_hook, shape in cases:
+        batches = [torch.randn(*shape).cuda() for _ in range(3)]
+        harness._acc.reset()
+        state = orc.HookState()
+        h1 = module.register_forward_hook(hook)
+        h2 = module.register_forward_hook(lambda m, i, o: ref_hook(state, tuple(t.detach().cpu() for t in i), o.detach().cpu()))
+        with torch.no_grad():
+            for b in batches:
+                model(b)
+        h1.remove()
+        h2.remove()
+        got, ref = harness._acc.feature_result.cpu().double(), state.feature_result.double()
+        assert got.shape == ref.shape
+        nz = ref > 0
+        assert torch.all(got[~nz] == 0)
+        assert ((got[nz] - ref[nz]).abs() / ref[nz]).max().item() <= 1e-4
