@@ -258,6 +258,13 @@ def test_rows_that_are_not_dense(hw):
     assert torch.equal(got, dpa.energy_nc(view.contiguous(), algo=dpa.ALGO_RECT))
     sl = dpa.energy_nc(view, c_begin=3, c_count=5)
     assert torch.equal(sl, got[:, 3:8])
+    # batch-strided on top (samples 0 and 2 of four: maps are no longer one arithmetic sequence) and an odd front pad
+    base4 = synth(4, 11, h + 5, w + 7, 301 + h).cuda()
+    v2 = base4[::2, 2:9, 1:1 + h, 2:2 + w]
+    check(v2.cpu().contiguous(), dpa.energy_nc(v2))
+    if h % 2 == 0:
+        v3 = base4[::2, 2:9, 1:h, 2:1 + w]  # (h - 1) x (w - 1), odd H: padded back to h x w
+        check(v3.cpu().contiguous(), dpa.energy_nc(v3, pad_front_if_odd=True), pad_front_if_odd=True)
 
 
 @pytest.mark.parametrize("hw", [(7, 9), (9, 7), (13, 19), (55, 27), (63, 63)])
