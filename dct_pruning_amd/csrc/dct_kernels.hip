@@ -1239,6 +1239,62 @@ struct Fused2Cfg {
   static_assert(2 * BUF <= LDS_FLOATS, "LDS");
 };
 
+// ---- pass 1 of the two-roles kernel with the samples loaded straight into registers (DCTS_F2_REGLOAD) ------------------
+// The staged version brings a strip into LDS with direct-to-LDS loads, runs the role butterflies IN PLACE (16 reads, the
+// network, 16 writes per item) and then the role codelets read their rows: two LDS writes and two reads per sample, and
+// during pass 2 - no free buffer - nothing can stream in. Here an item's 16 samples x[a*M + p~][line] are buffer loads
+// (lane = line: 256 contiguous bytes per wave instruction; p is a compile-time constant of the wave, so every row offset
+// is an immediate and the rotation constants are literals), the network runs on them in registers and its outputs are
+// written once into the role image: one LDS write and one read per sample, one workgroup barrier per strip (the two
+// buffers alternate as images), no alignment requirement. The samples of the next strip are requested as soon as an
+// item's registers are free (they fly during the remaining butterflies, the barrier and the codelets); those of the next
+// map's first strip during pass 2, item by item as the dumps free registers.
+// Same box, % of the HBM peak, staged -> register loads -> + pass-2 rounds alternating between the two buffers (two barriers
+// per round instead of three): 288 x 288: 28.7 -> 30.4 -> 31.2 (2048 maps), 30.8 -> 33.0 -> 34.2 (4999), 27.3 -> 28.9 -> 29.5 (768);
+// 320 x 320: 29.7 -> 31.0 -> 31.5 (2048). 219 / 248 VGPRs, no scratch. On by default; 0 restores the staged pass 1.
+#ifndef DCTS_F2_REGLOAD
+#define DCTS_F2_REGLOAD 1
+#endif
+constexpr int kF2Out = 0x7ffffff0;  // a lane offset beyond any map: the load returns 0 and makes no request
+template <int M, int L, int P, int STRIP>
+__device__ __forceinline__ void f2_load_item(__amdgpu_buffer_rsrc_t rs, int voff, float (&y)[1 << L]) {
+  constexpr int S = 1 << L, N = M << L;
+  dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int s = decltype(i)::value;
+    constexpr int row = (s % 2 == 0) ? s * M + P : s * M + M - 1 - P;
+    y[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (row * N + STRIP * 64) * 4, 0));
+  });
+}
+template <int M, int L, int P>
+__device__ __forceinline__ void f2_network_store(float (&y)[1 << L], lds_ptr image, int rs_lds, int lane, bool act) {
+  constexpr int S = 1 << L;
+  constexpr RolePlan<L> plan{};
+  constexpr RotTable<M, L> tab{};
+  constexpr float sp = (P & 1) ? -1.f : 1.f;
+  dcts::static_for<plan.NOPS>([&](auto i) DCTS_LAMBDA_INLINE {
+    constexpr int o = decltype(i)::value;
+    constexpr int a = plan.op_a[o], bb = plan.op_b[o], r = plan.op_rot[o];
+    const float ya = y[a], yb = y[bb];
+    if constexpr (r < 0) {
+      y[a] = ya + yb;
+      y[bb] = ya - yb;
+    } else {
+      constexpr float c = tab.c[r][P], sn = tab.s[r][P];
+      constexpr float k0 = RotTable<M, L>::sign0(r);
+      y[a] = ya * c + yb * sn;
+      y[bb] = (k0 * sp) * (yb * c - ya * sn);
+    }
+  });
+  if (act) {
+    lds_ptr colp = image + lane;
+    dcts::static_for<S>([&](auto i) DCTS_LAMBDA_INLINE {
+      constexpr int s = decltype(i)::value;
+      constexpr int row = (s % 2 == 0) ? s * M + P : s * M + M - 1 - P;
+      colp[row * rs_lds] = y[s];
+    });
+  }
+}
+
 template <int M, int L, int W, bool STORE = false>
 __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, lds_ptr buf1, lds_ptr partials,
                                             int lane_in, float* leaf_out = nullptr) {
@@ -1265,14 +1321,79 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
       if constexpr (!STORE) *tile_out(tb, mm, &hint_out) = t * sc;
     }
   };
+  // register-load pass 1: this wave's butterfly items are p = W, W + NW, ... (compile time); pre[i] holds item i's samples
+  constexpr int ITEMS = (M - W + NW - 1) / NW;
+  static_assert(ITEMS <= ROUNDS, "one item of the next map per pass-2 round");
+  float pre[DCTS_F2_REGLOAD ? ITEMS : 1][1 << L];
+  auto map_rsrc = [&](const float* base, bool valid) DCTS_LAMBDA_INLINE {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, valid ? (unsigned)(N * N * 4) : 0u, 0x00020000);
+  };
+  auto lane_voff = [&](int strip) DCTS_LAMBDA_INLINE {
+    const int lane = launder(lane_in);
+    return (strip * SW + lane < N) ? lane * 4 : kF2Out;
+  };
   if (m < nmaps) {
     const float* first = tile_in(tb, m);
+    if constexpr (DCTS_F2_REGLOAD) {
+      const __amdgpu_buffer_rsrc_t rs = map_rsrc(first, true);
+      const int vo = lane_voff(0);
+      dcts::static_for<ITEMS>([&](auto ii) DCTS_LAMBDA_INLINE {
+        constexpr int i = decltype(ii)::value;
+        f2_load_item<M, L, W + NW * i, 0>(rs, vo, pre[i]);
+      });
+    } else {
 #pragma unroll
-    for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(first, 0, buf0, lane_in, W, it);
+      for (int it = 0; it < Stage::PIECES; ++it) Stage::piece_raw(first, 0, buf0, lane_in, W, it);
+    }
   }
   for (; m < nmaps; m += gridDim.x) {
     const float* in_b = tile_in(tb, m, &hint_in);
     float parked[2][STRIPS][M];
+#if DCTS_F2_REGLOAD
+    const bool more_maps = m + gridDim.x < nmaps;
+    const float* next_b = more_maps ? tile_in(tb, m + gridDim.x, &hint_next) : in_b;
+    // ---- pass 1: H axis, strip by strip; butterflies on samples in registers, one barrier per strip ------------
+    dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
+      constexpr int s = decltype(is)::value;
+      const lds_ptr buf = cur ? buf1 : buf0;
+      int lane = launder(lane_in);
+      const bool act = s * SW + lane < N;
+      DCTS_STAMP(2);
+      {
+        const __amdgpu_buffer_rsrc_t rs = map_rsrc(in_b, true);
+        const int vo = (s + 1 < STRIPS) ? lane_voff(s + 1) : 0;
+        dcts::static_for<ITEMS>([&](auto ii) DCTS_LAMBDA_INLINE {
+          constexpr int i = decltype(ii)::value;
+          f2_network_store<M, L, W + NW * i>(pre[i], buf, SW, lane, act);
+          // the registers of this item are free: request its samples of the next strip
+          if constexpr (s + 1 < STRIPS) f2_load_item<M, L, W + NW * i, (s + 1 < STRIPS ? s + 1 : 0)>(rs, vo, pre[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      DCTS_STAMP(3);
+      lds_barrier();  // the image of strip s is complete; everyone is past the codelets of strip s - 1 (the other buffer)
+      DCTS_STAMP(4);
+      if constexpr (s == 0) {
+        if (pending_m >= 0) {
+          finish(partials, pending_slot, pending_m);
+          pending_m = -1;
+        }
+      }
+      dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
+        constexpr int i = decltype(ii)::value;
+        const int ln = launder(lane_in);
+        float o[M];
+        split_role_transform<M, L, 2 * W + i>(buf + (act ? ln : 0), SW, o);
+        dcts::static_for<M>([&](auto ik) DCTS_LAMBDA_INLINE {
+          constexpr int k = decltype(ik)::value;
+          asm volatile("" : "+v"(o[k]));  // pin the codelet here (LLVM would sink it to the dump)
+          parked[i][s][k] = o[k];
+        });
+      });
+      DCTS_STAMP(5);
+      cur ^= 1;
+    });
+#else
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
       constexpr int s = decltype(is)::value;
@@ -1329,13 +1450,20 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
       DCTS_STAMP(5);
       cur ^= 1;
     });
+#endif
     // ---- pass 2: W axis, KPR coefficients of every role per round ---------------------------
-    const lds_ptr blk = cur ? buf0 : buf1;  // the last strip's buffer; the other one is receiving
+    const lds_ptr blk0 = cur ? buf0 : buf1;  // the last strip's buffer; the other one is receiving (staged) / free (register loads)
+    const lds_ptr blk1 = cur ? buf1 : buf0;
+    // With the samples loaded into registers nothing streams into the second buffer during pass 2: the rounds alternate
+    // between the two, and a round's dump need not wait for the readers of the previous round (they use the other buffer;
+    // the readers of the round before that are two barriers back): two barriers per round instead of three.
+    constexpr bool ALT = DCTS_F2_REGLOAD != 0;
     float e = 0.f;
     dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(ir)::value;
+      const lds_ptr blk = (ALT && r % 2 == 1) ? blk1 : blk0;
       DCTS_STAMP(11);
-      lds_barrier();  // previous readers of blk are done
+      if constexpr (!ALT || r == 0) lds_barrier();  // previous readers of blk are done
       DCTS_STAMP(6);
       int lane = launder(lane_in);
       dcts::static_for<2>([&](auto ii) DCTS_LAMBDA_INLINE {
@@ -1355,6 +1483,12 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
         });
       });
       DCTS_STAMP(7);
+#if DCTS_F2_REGLOAD
+      if constexpr (r < ITEMS) {  // round r's dump has freed registers: item r of the next map's first strip
+        const __amdgpu_buffer_rsrc_t rs = map_rsrc(next_b, more_maps);
+        f2_load_item<M, L, W + NW * (r < ITEMS ? r : 0), 0>(rs, lane_voff(0), pre[r < ITEMS ? r : 0]);
+      }
+#endif
       lds_barrier();
       DCTS_STAMP(8);
       lane = launder(lane_in);
@@ -1397,11 +1531,13 @@ __device__ __forceinline__ void fused2_body(const TileBatch& tb, lds_ptr buf0, l
       // no room for a partials array: it lives behind the image, and the sum is taken right away
       // (the next strip only streams into this buffer after the next top-of-strip barrier)
       lds_barrier();  // every wave has finished reading the image
+      const lds_ptr blk = (ALT && (ROUNDS - 1) % 2 == 1) ? blk1 : blk0;  // the last round's buffer
       const lds_ptr part = blk + N * RW;
       if (lane_in == 0) part[W] = e;
       lds_barrier();
       finish(part, 0, m);
     }
+    if constexpr (DCTS_F2_REGLOAD != 0 && ROUNDS % 2 == 0) cur ^= 1;  // the next map's first strip must not overwrite the last round's image
   }
   if (pending_m >= 0) {
     lds_barrier();
@@ -2704,8 +2840,9 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
     if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) {
       int fam = (split_ok && aligned16) ? tile_family((int)HP, algo, g.nmaps) : 0;
-      if (!fam && dense_maps && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_TILE2D)) {
+      if (!fam && dense_maps && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_TILE2D || (algo == DCTS_ALGO_FUSED && has_fused2(HP)))) {
         if (pad == 0 && !aligned16 && dctsi::has_tile2g((int)HP)) fam = 5;
+        if (pad == 0 && !aligned16 && has_fused2(HP) && DCTS_F2_REGLOAD) fam = 2;  // the two-roles kernel loads dwords into registers
         if (pad == 1 && dctsi::has_tile2g_pad((int)HP)) fam = 6;
       }
       if (fam) {
@@ -3002,9 +3139,9 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
   for (int32_t i = 0; i < count; ++i) {
     const dcts_tensor_item& t = items[i];
     const float* x0 = t.x + (int64_t)t.c_begin * t.strideC;
-    // (the dword-gathering tile2g kernels - families 5 and 6 - take any 4-byte-aligned base, the others need 16)
+    // (the dword-loading kernels - tile2g, families 5 and 6, and the two-roles kernel, family 2 - take any 4-byte-aligned base, the others need 16)
     const bool dense = fam && t.strideC == H * W && (t.N == 1 || t.strideN == (int64_t)t.c_count * t.strideC) &&
-                       ((reinterpret_cast<uintptr_t>(x0) & 15) == 0 || fam >= 5);
+                       ((reinterpret_cast<uintptr_t>(x0) & 15) == 0 || fam >= 5 || (fam == 2 && DCTS_F2_REGLOAD));
     if (dense) {
       if (nb == 0) tb.begin[0] = 0;
       tb.x[nb] = x0;
