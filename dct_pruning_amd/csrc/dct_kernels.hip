@@ -1024,6 +1024,19 @@ __device__ __forceinline__ void fused_finish(lds_ptr partials, int slot, long lo
 // STORE: debug / parity instantiation (dcts_dct2d_f32_ex with DCTS_ALGO_FUSED): the weighted leaf outputs
 // of pass 2 also go to leaf_out[map][roleH * M + kH][roleW * M + kW]; k_assemble (split_roles.hpp) applies
 // the DCT-IV add/sub layers the energy path folds into its weights. No energy is written.
+// (defined with the two-roles kernel below)
+template <int M, int L, int P, int STRIP>
+__device__ __forceinline__ void f2_load_item(__amdgpu_buffer_rsrc_t rs, int voff, float (&y)[1 << L]);
+template <int M, int L, int P>
+__device__ __forceinline__ void f2_network_store(float (&y)[1 << L], lds_ptr image, int rs_lds, int lane, bool act);
+// The one-role-per-wave fused kernel with pass 1 on samples loaded into registers and alternating pass-2 buffers (see
+// DCTS_F2_REGLOAD below). Same box, staged -> register loads, % of the HBM peak: 96: 38.1 -> 43.2, 192: 33.0 -> 33.9, 256: 35.3 -> 35.8
+// (762 maps) / 39.0 -> 41.0 (3000), 112: 38.2 -> 38.3; the shapes AUTO gives to other kernels: 128 45.3 -> 48.9, 144 31.9 -> 34.6,
+// 224 29.4 -> 30.8, 160 32.9 -> 33.8, 72 33.4 -> 31.8. No scratch (one coefficient instantiation: 12 B).
+#ifndef DCTS_F1_REGLOAD
+#define DCTS_F1_REGLOAD 1
+#endif
+
 template <int M, int L, int ROLE, bool STORE = false>
 __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds_ptr partials, int lane,
                                            float* leaf_out = nullptr) {
@@ -1039,14 +1052,67 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
 #endif
   const long long nmaps = tb.total;
   int hint_in = 0, hint_next = 0, hint_out = 0;  // tensor of the current / next / finished map (tile_item)
+  constexpr int ITEMS = ROLE < M ? (M - ROLE + S - 1) / S : 0;  // this wave's butterfly items p = ROLE, ROLE + S, ...
+  static_assert(ITEMS <= ROUNDS, "one item of the next map per pass-2 round");
+  float pre[DCTS_F1_REGLOAD && ITEMS > 0 ? ITEMS : 1][1 << L];
+  auto map_rsrc = [&](const float* base, bool valid) DCTS_LAMBDA_INLINE {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, valid ? (unsigned)(N * N * 4) : 0u, 0x00020000);
+  };
+  auto lane_voff = [&](int strip) DCTS_LAMBDA_INLINE {
+    const int ln = launder(lane);
+    return (strip * SW + ln < N) ? ln * 4 : 0x7ffffff0;
+  };
   if (m < nmaps) {
     const float* first = tile_in(tb, m);
+    if constexpr (DCTS_F1_REGLOAD != 0) {
+      const __amdgpu_buffer_rsrc_t rs = map_rsrc(first, true);
+      const int vo = lane_voff(0);
+      dcts::static_for<ITEMS>([&](auto ii) DCTS_LAMBDA_INLINE {
+        constexpr int i = decltype(ii)::value;
+        f2_load_item<M, L, ROLE + S * i, 0>(rs, vo, pre[i]);
+      });
+    } else {
 #pragma unroll
-    for (int it = 0; it < FusedStage<M, L>::PIECES; ++it) FusedStage<M, L>::piece_raw(first, 0, lds, lane, ROLE, it);
+      for (int it = 0; it < FusedStage<M, L>::PIECES; ++it) FusedStage<M, L>::piece_raw(first, 0, lds, lane, ROLE, it);
+    }
   }
   for (; m < nmaps; m += gridDim.x) {
     const float* in_b = tile_in(tb, m, &hint_in);
     float parked[STRIPS][M];
+#if DCTS_F1_REGLOAD
+    const bool more_maps = m + gridDim.x < nmaps;
+    const float* next_b = more_maps ? tile_in(tb, m + gridDim.x, &hint_next) : in_b;
+    // ---- pass 1 on samples in registers: one barrier per strip, the two buffers alternate as role images ---------------
+    dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
+      constexpr int s = decltype(is)::value;
+      const lds_ptr buf = lds + cur * BUF;
+      const int ln = launder(lane);
+      const bool act = s * SW + ln < N;
+      DCTS_STAMP(2);
+      {
+        const __amdgpu_buffer_rsrc_t rs = map_rsrc(in_b, true);
+        const int vo = (s + 1 < STRIPS) ? lane_voff(s + 1) : 0;
+        dcts::static_for<ITEMS>([&](auto ii) DCTS_LAMBDA_INLINE {
+          constexpr int i = decltype(ii)::value;
+          f2_network_store<M, L, ROLE + S * i>(pre[i], buf, SW, ln, act);
+          if constexpr (s + 1 < STRIPS) f2_load_item<M, L, ROLE + S * i, (s + 1 < STRIPS ? s + 1 : 0)>(rs, vo, pre[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+      DCTS_STAMP(3);
+      lds_barrier();
+      DCTS_STAMP(4);
+      if constexpr (s == 0) {
+        if (pending_m >= 0) {
+          if constexpr (!STORE) fused_finish<M, L, ROLE>(partials, pending_slot, pending_m, tb, lane, &hint_out);
+          pending_m = -1;
+        }
+      }
+      split_role_transform<M, L, ROLE>(buf + (act ? launder(lane) : 0), SW, parked[s]);
+      DCTS_STAMP(5);
+      cur ^= 1;
+    });
+#else
     // ---- pass 1: H axis, strip by strip -------------------------------------------------
     dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
       constexpr int s = decltype(is)::value;
@@ -1085,13 +1151,17 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
       DCTS_STAMP(5);
       cur ^= 1;
     });
+#endif
     // ---- pass 2: W axis, RPR role groups of parked rows per round ---------------------------
-    const lds_ptr blk = lds + (cur ^ 1) * BUF;  // the last strip's buffer; the other one is receiving
+    const lds_ptr blk0 = lds + (cur ^ 1) * BUF;  // the last strip's buffer; the other one is receiving (staged) / free (register loads)
+    const lds_ptr blk1 = lds + cur * BUF;
+    constexpr bool ALT = DCTS_F1_REGLOAD != 0;  // rounds alternate between the buffers: two barriers per round (see fused2_body)
     float e = 0.f;
     dcts::static_for<ROUNDS>([&](auto ir) DCTS_LAMBDA_INLINE {
       constexpr int r = decltype(ir)::value;
+      const lds_ptr blk = (ALT && r % 2 == 1) ? blk1 : blk0;
       DCTS_STAMP(11);
-      lds_barrier();  // previous readers of blk are done
+      if constexpr (!ALT || r == 0) lds_barrier();  // previous readers of blk are done
       DCTS_STAMP(6);
       if constexpr (Cfg::BALANCED) {
         dcts::static_for<STRIPS>([&](auto is) DCTS_LAMBDA_INLINE {
@@ -1119,6 +1189,12 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
         });
       }
       DCTS_STAMP(7);
+#if DCTS_F1_REGLOAD
+      if constexpr (r < ITEMS) {  // item r of the next map's first strip
+        const __amdgpu_buffer_rsrc_t rs = map_rsrc(next_b, more_maps);
+        f2_load_item<M, L, ROLE + S * (r < ITEMS ? r : 0), 0>(rs, lane_voff(0), pre[r < ITEMS ? r : 0]);
+      }
+#endif
       lds_barrier();
       DCTS_STAMP(8);
       // columns of this round: all of them, or fewer whole roles in the last unbalanced round
@@ -1162,6 +1238,7 @@ __device__ __forceinline__ void fused_body(const TileBatch& tb, lds_ptr lds, lds
     pending_m = m;
     pending_slot = pslot;
     pslot ^= 1;
+    if constexpr (DCTS_F1_REGLOAD != 0 && ROUNDS % 2 == 0) cur ^= 1;  // the next map's first strip must not overwrite the last round's image
     DCTS_STAMP(13);
   }
   if (pending_m >= 0) {
@@ -2840,10 +2917,12 @@ int run(const float* x, int64_t N, int64_t C_total, int64_t H, int64_t W, int64_
     if (algo == DCTS_ALGO_SPLIT && !split_ok) return DCTS_E_UNSUPPORTED;
     if (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_FUSED || algo == DCTS_ALGO_PIPE || algo == DCTS_ALGO_TILE2D) {
       int fam = (split_ok && aligned16) ? tile_family((int)HP, algo, g.nmaps) : 0;
-      if (!fam && dense_maps && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_TILE2D || (algo == DCTS_ALGO_FUSED && has_fused2(HP)))) {
-        if (pad == 0 && !aligned16 && dctsi::has_tile2g((int)HP)) fam = 5;
-        if (pad == 0 && !aligned16 && has_fused2(HP) && DCTS_F2_REGLOAD) fam = 2;  // the two-roles kernel loads dwords into registers
-        if (pad == 1 && dctsi::has_tile2g_pad((int)HP)) fam = 6;
+      if (!fam && dense_maps && (algo == DCTS_ALGO_AUTO || algo == DCTS_ALGO_TILE2D || algo == DCTS_ALGO_FUSED)) {
+        const bool t2 = algo != DCTS_ALGO_FUSED, fu = algo != DCTS_ALGO_TILE2D;  // an explicit family request is kept
+        if (t2 && pad == 0 && !aligned16 && dctsi::has_tile2g((int)HP)) fam = 5;
+        if (!fam && fu && pad == 0 && !aligned16 && has_fused2(HP) && DCTS_F2_REGLOAD) fam = 2;  // the two-roles kernel loads dwords into registers
+        if (!fam && fu && pad == 0 && !aligned16 && has_fused(HP) && DCTS_F1_REGLOAD) fam = 1;   // so does the fused kernel
+        if (t2 && pad == 1 && dctsi::has_tile2g_pad((int)HP)) fam = 6;
       }
       if (fam) {
         TileBatch tb;
@@ -3141,7 +3220,7 @@ int dcts_energy_multi_f32(const dcts_tensor_item* items, int32_t count, int64_t 
     const float* x0 = t.x + (int64_t)t.c_begin * t.strideC;
     // (the dword-loading kernels - tile2g, families 5 and 6, and the two-roles kernel, family 2 - take any 4-byte-aligned base, the others need 16)
     const bool dense = fam && t.strideC == H * W && (t.N == 1 || t.strideN == (int64_t)t.c_count * t.strideC) &&
-                       ((reinterpret_cast<uintptr_t>(x0) & 15) == 0 || fam >= 5 || (fam == 2 && DCTS_F2_REGLOAD));
+                       ((reinterpret_cast<uintptr_t>(x0) & 15) == 0 || fam >= 5 || (fam == 2 && DCTS_F2_REGLOAD) || (fam == 1 && DCTS_F1_REGLOAD));
     if (dense) {
       if (nb == 0) tb.begin[0] = 0;
       tb.x[nb] = x0;

@@ -635,12 +635,11 @@ def test_weighted_calls_of_several_shapes_share_one_workspace_safely():
     assert ops._workspace(dev, stream, 1).data_ptr() == base  # one buffer throughout
 
 
-@pytest.mark.parametrize("n", [72, 288])
+@pytest.mark.parametrize("n", [72, 256, 288])
 def test_large_tile_with_a_4_byte_aligned_base(n):
-    """The strip-staging split kernels use 16-byte direct-to-LDS loads; a view whose base is only 4-byte aligned is refused by
-    them (two-launch path; the fused kernel at 72). The kernels that load single dwords take it: tile2g.hip (72) and, since
-    round 3, the two-roles kernel (288: samples straight into registers) - under AUTO the same kernel, aligned or not, and the
-    same bits."""
+    """The two-launch path stages with 16-byte direct-to-LDS loads and refuses a view whose base is only 4-byte aligned. The
+    kernels that load single dwords take it: tile2g.hip (72) and, since round 3, the fused and the two-roles kernels (256, 288:
+    samples straight into registers) - under AUTO the same kernel, aligned or not, and the same bits."""
     from dct_pruning_amd._lib import DctScoreError
     c = 3
     x = synth(1, c, n, n, 700 + n)
@@ -651,12 +650,13 @@ def test_large_tile_with_a_4_byte_aligned_base(n):
     got = dpa.energy_nc(view).cpu()
     ref = torch.from_numpy(orc.energy_nc_f64(x)).float()
     assert rel_err(got, ref) <= RTOL
-    for algo in ((dpa.ALGO_FUSED, dpa.ALGO_SPLIT) if n == 72 else (dpa.ALGO_SPLIT,)):
-        with pytest.raises(DctScoreError) as ei:
-            dpa.energy_nc(view, algo=algo)
-        assert ei.value.code == -6  # DCTS_E_UNSUPPORTED
-    if n == 288:
-        assert torch.equal(dpa.energy_nc(view, algo=dpa.ALGO_FUSED).cpu(), got)
+    with pytest.raises(DctScoreError) as ei:
+        dpa.energy_nc(view, algo=dpa.ALGO_SPLIT)
+    assert ei.value.code == -6  # DCTS_E_UNSUPPORTED
+    fused = dpa.energy_nc(view, algo=dpa.ALGO_FUSED).cpu()
+    assert torch.equal(fused, dpa.energy_nc(x.cuda(), algo=dpa.ALGO_FUSED).cpu())
+    if n != 72:
+        assert torch.equal(fused, got)  # AUTO is the fused family there
     # the aligned tensor itself goes through the same large-tile kernel: the same bits
     assert torch.equal(dpa.energy_nc(x.cuda()).cpu(), got)
 
