@@ -661,6 +661,25 @@ def test_large_tile_with_a_4_byte_aligned_base(n):
     assert torch.equal(dpa.energy_nc(x.cuda()).cpu(), got)
 
 
+@pytest.mark.parametrize("n", [96, 112, 128, 144, 192, 224, 320])
+def test_4_byte_aligned_base_every_large_shape(n):
+    """The other large shapes on a base that is only 4-byte aligned: a factorised kernel that loads dwords (the fused family, tile2g)
+    instead of the cosine-matrix kernel; against the oracle on a few maps and Parseval on all."""
+    c = 37
+    x = synth(1, c, n, n, 900 + n)
+    flat = torch.zeros(c * n * n + 1)
+    flat[1:] = x.reshape(-1)
+    view = flat.cuda()[1:].view(1, c, n, n)
+    assert view.data_ptr() % 16 == 4
+    got = dpa.energy_nc(view).cpu()
+    par = (x.double() ** 2).sum(dim=(-2, -1))
+    nz = par > 0
+    assert ((got.double()[nz] - par[nz]).abs() / par[nz]).max().item() <= 1e-5 and (got[~nz] == 0).all()
+    ref = torch.from_numpy(orc.energy_nc_f64(x[:, :6])).float()
+    assert rel_err(got[:, :6], ref) <= RTOL
+    assert rel_err(dpa.energy_nc(view, algo=dpa.ALGO_DIRECT).cpu(), got) <= 1e-5
+
+
 def test_published_jpeg_worked_example_on_gpu():
     """The published 8x8 worked example of the JPEG literature (tests/golden/jpeg_example_8x8.json: data typed from the
     publication) through the product's coefficient path, codelet and direct kernels: a known answer that comes from
